@@ -1,0 +1,160 @@
+/*
+ * rt_mi355x.h — C ABI of the MI355X path-tracing core (librt_mi355x.so).
+ *
+ * The reference renderer has no plugin or FFI layer: its tracer sits behind OpenGL, i.e. behind
+ * a fixed set of named uniforms, buffers and one full-screen draw per frame. Each entry point
+ * below replaces one of those GL-side interfaces (cited per function as file:line of the
+ * reference). A host program that today fills those uniforms/buffers and calls glDrawArrays can
+ * call these functions instead and read the same image back.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative rt_status otherwise; rt_last_error()
+ *     gives the message. Nothing aborts, nothing throws across this boundary.
+ *   - pointers are caller-owned host memory unless the name says "device"; they are only read
+ *     (or written) during the call.
+ *   - one caller thread per context (the reference is single-threaded around one GL context).
+ *   - state is sticky between frames, like GL uniforms.
+ *   - work is queued on the context's HIP stream; rt_sync / rt_accum_read / rt_postprocess wait.
+ *   - images are rows of RGBA float (or RGB byte) pixels, row 0 = BOTTOM row, x to the right,
+ *     exactly what glGetTexImage returns for the reference's textures.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / inconsistent scene arrays */
+    RT_ERR_DEVICE = -2,      /* HIP runtime error (no GPU, out of memory, launch failure) */
+    RT_ERR_STATE = -3,       /* call made before the data it needs was uploaded */
+    RT_ERR_UNSUPPORTED = -4  /* scene exceeds a documented limit */
+};
+
+/* One entry of the shader's `uniform Material u_Materials[16]` (src/shaders/Fragment.glsl:15-23,90),
+ * filled by Scene::SendSceneMaterials (src/Scene.cpp:133-153). */
+typedef struct rt_material {
+    float colour[3];
+    float specularColour[3];
+    float roughness;
+    float metallic;
+    float transparency;      /* luminance for light sources (Include/Materials.h:46-48) */
+    float refractionIndex;
+    int32_t isLight;
+} rt_material;
+
+/* `uniform Camera u_Camera` (src/shaders/Fragment.glsl:57-63,74); set by Scene::Scene
+ * (src/Scene.cpp:20-22) and Camera::UploadInfo (src/Camera.cpp:129-135). */
+typedef struct rt_camera {
+    float position[3];
+    float facing[3];
+    float fov;               /* radians; carried for completeness, the tracer does not read it */
+    float viewportWidth;
+    float viewportDistance;
+} rt_camera;
+
+/* Per-context counters accumulated by rt_render since the last reset. */
+typedef struct rt_counters {
+    uint64_t rays;           /* BVH traversals (primary + bounce segments): Fragment.glsl:385 */
+    uint64_t node_pops;      /* sum of the shader's iterationsCount */
+    uint64_t boxes_tested;   /* distinct bounding boxes tested */
+    uint64_t tris_tested;    /* triangle intersection tests */
+    uint64_t noise_fetches;  /* texture(u_RgbNoise, ...) calls */
+    uint64_t sky_fetches;    /* texture(u_Skybox, ...) calls */
+    uint64_t paths;          /* pixel samples finished */
+} rt_counters;
+
+/* Library-level message for failures that happen before a context exists (rt_create). */
+const char *rt_last_global_error(void);
+const char *rt_last_error(const rt_context *ctx);
+
+/* Creates a renderer for a width x height image on HIP device `device`.
+ * Replaces: window/FBO/accumulation-texture setup and `uniform vec2 screenResolution`
+ * (src/main.cpp:28-29,38-39,144-158). The accumulation image starts at zero. */
+int rt_create(int device, uint32_t width, uint32_t height, rt_context **out);
+void rt_destroy(rt_context *ctx);
+
+/* Uploads the flattened scene. Replaces the three buffer uploads of Scene::LoadObjects
+ * (src/Scene.cpp:120-126):
+ *   tri12   float[12*nTri]  xyz0 per corner           (SSBO binding 0, Fragment.glsl:44-47)
+ *   matIdx  int32[nTri]     material slot per triangle (u_MaterialsIndex, Fragment.glsl:85)
+ *   node8   float[8*nNode]  max.xyz, min.xyz, float(triCount), float(triStart | rightChild),
+ *                           nodes in pre-order, first child = parent + 1
+ *                           (u_BoundingBoxes / u_BoundingBoxesCount, Fragment.glsl:87-88,195-205)
+ * The arrays are validated (indices in range, tree well-formed, depth <= 64, leaves <= 16
+ * triangles, nTri < 2^24) and re-laid-out for the GPU; nNode == 0 gives an empty scene. */
+int rt_scene_upload(rt_context *ctx, const float *tri12, const int32_t *matIdx, uint32_t nTri,
+                    const float *node8, uint32_t nNode);
+
+/* Replaces Scene::SendSceneMaterials (src/Scene.cpp:133-153). count <= 16. */
+int rt_set_materials(rt_context *ctx, const rt_material *materials, uint32_t count);
+
+/* Replaces Camera::UploadInfo + the constructor-time camera uniforms. */
+int rt_set_camera(rt_context *ctx, const rt_camera *camera);
+
+/* Replaces glUniform1ui(u_BounceLimit) (src/Scene.cpp:19, src/BounceLimitManager.cpp:14-48).
+ * 0 = BVH heat map, 1 = |normal| of the primary hit, n >= 2 = path tracing. */
+int rt_set_bounce_limit(rt_context *ctx, uint32_t bounceLimit);
+
+/* Replaces LoadNoiseTexture (src/main.cpp:89-114): RGB8, rows bottom-up as uploaded to GL
+ * (i.e. in file order, the reference does not flip), LINEAR filter, REPEAT wrap. */
+int rt_set_noise(rt_context *ctx, const uint8_t *rgb, uint32_t width, uint32_t height);
+
+/* Replaces LoadSkybox (src/main.cpp:45-87): six RGBA8 size x size faces in GL order
+ * +X,-X,+Y,-Y,+Z,-Z (= right,left,top,bottom,front,back), LINEAR, CLAMP_TO_EDGE. */
+int rt_set_skybox(rt_context *ctx, const uint8_t *const faces[6], uint32_t size);
+
+/* Accumulation image (`u_Accumulation`, also the render target: src/main.cpp:148-158). */
+int rt_accum_clear(rt_context *ctx);
+int rt_accum_write(rt_context *ctx, const float *rgba);
+int rt_accum_read(rt_context *ctx, float *rgba);
+
+/* Renders nFrames progressive frames. Frame k uses u_FrameIndex = firstFrameIndex + k and
+ * u_RandSeed = seeds3[3k..3k+2]; replaces Scene::Tick's two uniforms plus the tracer draw
+ * (src/Scene.cpp:30-31, src/main.cpp:232-233). Seeds are always explicit. */
+int rt_render(rt_context *ctx, uint32_t firstFrameIndex, uint32_t nFrames, const float *seeds3);
+int rt_sync(rt_context *ctx);
+
+/* Parity channel: traces only the primary rays of one frame and returns, per pixel,
+ * {triangle index or -1, bit pattern of t, iterationsCount}. No counterpart in the reference's
+ * output (it emits colours only); it exposes the values Fragment.glsl:265-326 computes. */
+int rt_primary_ids(rt_context *ctx, const float *seed3, int32_t *out3);
+
+/* Bloom chain + final composite of one frame (src/main.cpp:242-275 with
+ * extractBrightFragment.glsl, bloomFragment.glsl, finalFragment.glsl); bloom_on == 0 is the
+ * raw blit of src/main.cpp:235-240. Either output may be NULL. rgb8_out is what
+ * Recorder::WriteTexture reads back (Include/Recorder.h:93-100). */
+int rt_postprocess(rt_context *ctx, int bloom_on, float *rgba_out, uint8_t *rgb8_out);
+
+int rt_get_counters(rt_context *ctx, rt_counters *out, int reset);
+
+/* ---- multi-GPU tile sharding (no counterpart in the reference, which is single-GPU) ----
+ * The image is cut into 8x8-pixel tiles, tile t = ty * tilesX + tx. With a shard (rank, world)
+ * a context renders only tiles with t % world == rank and keeps them contiguous in device
+ * memory, 64 RGBA float pixels per tile, local tile j = global tile j * world + rank. */
+int rt_set_shard(rt_context *ctx, uint32_t rank, uint32_t world);
+/* Number of tiles every rank's shard buffer holds (ceil(tiles / world); tail tiles are padding). */
+int rt_shard_tiles(const rt_context *ctx, uint32_t *tilesPerRank);
+/* Device pointer of this context's shard: tilesPerRank * 64 * 4 floats. */
+int rt_shard_device_ptr(rt_context *ctx, void **devicePtr);
+/* On the gathering rank: `gathered` is a device buffer holding world shards back to back in
+ * rank order (what a gather collective delivers). Scatters them into this context's image. */
+int rt_accum_assemble(rt_context *ctx, const void *gatheredDevice, uint32_t world);
+
+/* Queue this context's work on a caller-provided hipStream_t (NULL = the context's own). */
+int rt_set_stream(rt_context *ctx, void *hipStream);
+
+/* Timing of the tracer kernel launches made by rt_render since the last reset, measured with
+ * HIP events on the context's stream: total milliseconds and number of launches. */
+int rt_kernel_time(rt_context *ctx, double *ms_total, uint64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */
