@@ -133,6 +133,9 @@ int rt_primary_ids(rt_context *ctx, const float *seed3, int32_t *out3);
 int rt_postprocess(rt_context *ctx, int bloom_on, float *rgba_out, uint8_t *rgb8_out);
 
 int rt_get_counters(rt_context *ctx, rt_counters *out, int reset);
+/* full != 0: rt_render also tallies node pops, boxes, triangles and texture fetches (an
+ * instrumented kernel, a few percent slower). full == 0 (default): only rays and paths. */
+int rt_set_counting(rt_context *ctx, int full);
 
 /* ---- multi-GPU tile sharding (no counterpart in the reference, which is single-GPU) ----
  * The image is cut into 8x8-pixel tiles, tile t = ty * tilesX + tx. With a shard (rank, world)

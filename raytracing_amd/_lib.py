@@ -1,0 +1,93 @@
+"""Loads librt_mi355x.so (HIP kernels + C ABI + host scene model) and declares its signatures.
+
+There is no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+
+
+class rt_material(ctypes.Structure):
+    _fields_ = [("colour", ctypes.c_float * 3), ("specularColour", ctypes.c_float * 3), ("roughness", ctypes.c_float),
+                ("metallic", ctypes.c_float), ("transparency", ctypes.c_float), ("refractionIndex", ctypes.c_float),
+                ("isLight", ctypes.c_int32)]
+
+
+class rt_camera(ctypes.Structure):
+    _fields_ = [("position", ctypes.c_float * 3), ("facing", ctypes.c_float * 3), ("fov", ctypes.c_float),
+                ("viewportWidth", ctypes.c_float), ("viewportDistance", ctypes.c_float)]
+
+
+class rt_counters(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches",
+                                               "sky_fetches", "paths")]
+
+
+class rth_bvh_stats(ctypes.Structure):
+    _fields_ = [("max_depth", ctypes.c_int32), ("leaves", ctypes.c_uint32), ("splits", ctypes.c_uint64),
+                ("degenerate_splits", ctypes.c_uint64), ("leaf_depth_sum", ctypes.c_uint64), ("build_ms", ctypes.c_double)]
+
+
+# name -> (restype, argtypes); this table is also what the symbol-export test checks against the headers
+P, I, U32, U64P, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_float
+SIGNATURES = {
+    "rt_last_global_error": (ctypes.c_char_p, []),
+    "rt_last_error": (ctypes.c_char_p, [P]),
+    "rt_create": (I, [I, U32, U32, ctypes.POINTER(P)]),
+    "rt_destroy": (None, [P]),
+    "rt_scene_upload": (I, [P, P, P, U32, P, U32]),
+    "rt_set_materials": (I, [P, P, U32]),
+    "rt_set_camera": (I, [P, ctypes.POINTER(rt_camera)]),
+    "rt_set_bounce_limit": (I, [P, U32]),
+    "rt_set_noise": (I, [P, P, U32, U32]),
+    "rt_set_skybox": (I, [P, ctypes.POINTER(P), U32]),
+    "rt_accum_clear": (I, [P]),
+    "rt_accum_write": (I, [P, P]),
+    "rt_accum_read": (I, [P, P]),
+    "rt_render": (I, [P, U32, U32, P]),
+    "rt_sync": (I, [P]),
+    "rt_primary_ids": (I, [P, P, P]),
+    "rt_postprocess": (I, [P, I, P, P]),
+    "rt_get_counters": (I, [P, ctypes.POINTER(rt_counters), I]),
+    "rt_set_counting": (I, [P, I]),
+    "rt_set_shard": (I, [P, U32, U32]),
+    "rt_shard_tiles": (I, [P, ctypes.POINTER(U32)]),
+    "rt_shard_device_ptr": (I, [P, ctypes.POINTER(P)]),
+    "rt_accum_assemble": (I, [P, P, U32]),
+    "rt_set_stream": (I, [P, P]),
+    "rt_kernel_time": (I, [P, ctypes.POINTER(ctypes.c_double), U64P, I]),
+    "rth_scene_load": (I, [ctypes.POINTER(ctypes.c_char_p), U32, I, ctypes.POINTER(P)]),
+    "rth_scene_build": (I, [P, P, U32, P, U32, I, I, ctypes.POINTER(P)]),
+    "rth_scene_free": (None, [P]),
+    "rth_scene_triangle_count": (U32, [P]),
+    "rth_scene_node_count": (U32, [P]),
+    "rth_scene_material_count": (U32, [P]),
+    "rth_scene_tri12": (P, [P]),
+    "rth_scene_matidx": (P, [P]),
+    "rth_scene_node8": (P, [P]),
+    "rth_scene_materials": (P, [P]),
+    "rth_scene_stats": (None, [P, ctypes.POINTER(rth_bvh_stats)]),
+    "rth_scene_warning_count": (U32, [P]),
+    "rth_scene_warning": (ctypes.c_char_p, [P, U32]),
+    "rth_scene_send": (I, [P, P]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "librt_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C raytracing_amd/csrc`; there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,527 @@
+// Host side of the C ABI declared in include/rt_mi355x.h: owns the HIP resources of one
+// renderer, validates and re-lays-out the caller's flat scene arrays, and launches the kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+#include "rt_mi355x.h"
+
+namespace rtd {
+void LaunchTrace(int stackEntries, bool count, bool ids, hipStream_t st, uint32_t nBlocks, const SceneParams& sp, const FrameParams* frames,
+                 uint32_t nFrames, void* accum, uint32_t* tally, int32_t* idsOut);
+void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots);
+void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t width, uint32_t height, uint32_t tilesX, uint32_t world,
+                  uint32_t shardTiles, bool toTiled);
+int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint32_t height, int bloomOn, void** scratch,
+                   float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
+void FreePostprocess(void** scratch);
+}  // namespace rtd
+
+using namespace rtd;
+
+static thread_local std::string g_globalError;
+
+struct rt_context {
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    SceneParams sp{};
+    // device arrays
+    NodeRec* dNodes = nullptr; TriRec* dTris = nullptr; uint32_t* dNoise = nullptr; uint32_t* dSky = nullptr;
+    MaterialRec* dMaterials = nullptr;
+    void* dAccum = nullptr;          // tile-major shard, shardTiles*64 float4
+    void* dLinear = nullptr;         // row-major staging image, width*height float4
+    FrameParams* dFrames = nullptr; uint32_t framesCap = 0;
+    uint32_t* dTally = nullptr;      // [kCounterSlots][shardTiles]
+    unsigned long long* dTotals = nullptr;   // [kCounterSlots]
+    int32_t* dIds = nullptr;
+    void* postScratch = nullptr;
+    int stackEntries = 16;
+    bool haveNoise = false, haveSky = false, haveScene = false;
+    bool countAll = false;
+    uint64_t hostPaths = 0;          // pixel samples rendered while full counting was off
+    // kernel timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pendingEvents, freeEvents;
+    double kernelMs = 0.0; uint64_t kernelLaunches = 0;
+    std::string error;
+};
+
+namespace {
+
+int Fail(rt_context* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->error = buf; else g_globalError = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                         \
+    do { hipError_t e_ = (expr);                                                                 \
+         if (e_ != hipSuccess) return Fail((c), RT_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+inline float Flush(float v) { return std::fabs(v) < 1.17549435e-38f ? std::copysign(0.0f, v) : v; }   // FTZ/DAZ, as the kernels run
+
+uint32_t ShardTiles(const rt_context* c) {
+    uint32_t n = c->sp.tilesX * c->sp.tilesY;
+    return (n + c->sp.shardWorld - 1) / c->sp.shardWorld;
+}
+
+int AllocShard(rt_context* c) {
+    if (c->dAccum) { (void)hipFree(c->dAccum); c->dAccum = nullptr; }
+    if (c->dTally) { (void)hipFree(c->dTally); c->dTally = nullptr; }
+    if (c->dIds) { (void)hipFree(c->dIds); c->dIds = nullptr; }
+    c->sp.shardTiles = ShardTiles(c);
+    size_t bytes = (size_t)c->sp.shardTiles * 64 * sizeof(float) * 4;
+    HIP_TRY(c, hipMalloc(&c->dAccum, bytes));
+    HIP_TRY(c, hipMemsetAsync(c->dAccum, 0, bytes, c->stream));
+    size_t tb = (size_t)kCounterSlots * c->sp.shardTiles * sizeof(uint32_t);
+    HIP_TRY(c, hipMalloc((void**)&c->dTally, tb));
+    HIP_TRY(c, hipMemsetAsync(c->dTally, 0, tb, c->stream));
+    return RT_OK;
+}
+
+int ResolveEvents(rt_context* c) {
+    for (auto& pr : c->pendingEvents) {
+        HIP_TRY(c, hipEventSynchronize(pr.second));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+        c->kernelMs += ms; c->kernelLaunches++;
+        c->freeEvents.push_back(pr);
+    }
+    c->pendingEvents.clear();
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_global_error(void) { return g_globalError.c_str(); }
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : g_globalError.c_str(); }
+
+int rt_create(int device, uint32_t width, uint32_t height, rt_context** out) {
+    if (!out) return Fail(nullptr, RT_ERR_INVALID, "rt_create: out is NULL");
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 32768 || height > 32768) return Fail(nullptr, RT_ERR_INVALID, "rt_create: bad image size %ux%u", width, height);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return Fail(nullptr, RT_ERR_DEVICE, "rt_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return Fail(nullptr, RT_ERR_INVALID, "rt_create: device %d out of range (have %d)", device, count);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    rt_context* c = new rt_context();
+    c->device = device; c->width = width; c->height = height;
+    SceneParams& sp = c->sp;
+    sp.width = width; sp.height = height;
+    sp.tilesX = (width + kTile - 1) / kTile; sp.tilesY = (height + kTile - 1) / kTile;
+    sp.shardRank = 0; sp.shardWorld = 1;
+    sp.rootRef = kNoRef; sp.nNode = 0;
+    sp.bounceLimit = 4;                                   // src/Scene.cpp:19
+    sp.camPos[0] = sp.camPos[1] = sp.camPos[2] = 0.0f;    // Include/Camera.h:7-11
+    sp.camFacing[0] = 1.0f; sp.camFacing[1] = sp.camFacing[2] = 0.0f;
+    sp.vpD = 1.0f;
+    sp.vpW = (float)(2.0 * 1.0 * std::tan((float)(120 * 0.01745329251994329576923690768489) / 2.0));   // src/Camera.cpp:14,19
+    const float a = (float)(-3.1415 / 2);                 // Fragment.glsl:406
+    sp.skyCos = std::cos(a); sp.skySin = std::sin(a);
+    hipError_t se = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return Fail(nullptr, RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(se)); }
+    c->stream = c->ownStream;
+    int rc = AllocShard(c);
+    if (rc == RT_OK) {
+        hipError_t me = hipMalloc((void**)&c->dMaterials, sizeof(MaterialRec) * kMaxMaterials);
+        if (me == hipSuccess) me = hipMemsetAsync(c->dMaterials, 0, sizeof(MaterialRec) * kMaxMaterials, c->stream);
+        if (me == hipSuccess) me = hipMalloc((void**)&c->dTotals, sizeof(unsigned long long) * kCounterSlots);
+        if (me == hipSuccess) me = hipMemsetAsync(c->dTotals, 0, sizeof(unsigned long long) * kCounterSlots, c->stream);
+        if (me == hipSuccess) me = hipMalloc(&c->dLinear, (size_t)width * height * 16);
+        if (me != hipSuccess) rc = Fail(c, RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(me));
+    }
+    if (rc != RT_OK) { g_globalError = c->error; rt_destroy(c); return rc; }
+    sp.materials = c->dMaterials;
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& pr : c->pendingEvents) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : c->freeEvents) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    FreePostprocess(&c->postScratch);
+    void* ptrs[] = {c->dNodes, c->dTris, c->dNoise, c->dSky, c->dMaterials, c->dAccum, c->dLinear, c->dFrames, c->dTally, c->dTotals, c->dIds};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, uint32_t nTri, const float* node8, uint32_t nNode) {
+    if (!c) return RT_ERR_INVALID;
+    if ((nTri && (!tri12 || !matIdx)) || (nNode && !node8)) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: NULL array");
+    if (nTri >= (1u << 24)) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: %u triangles; indices travel as floats and are exact only below 2^24", nTri);
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    // ---- validate the pre-order tree and measure its depth (iteratively; no recursion) ----
+    struct Info { int count; int ref; };
+    auto info = [&](uint32_t i) { Info r; r.count = (int)node8[(size_t)i * 8 + 6]; r.ref = (int)node8[(size_t)i * 8 + 7]; return r; };
+    std::vector<NodeRec> nodes(nNode);
+    int maxInteriorDepth = 0;
+    if (nNode) {
+        std::vector<std::pair<uint32_t, int>> todo;   // (node, depth), root depth 1
+        std::vector<uint8_t> seen(nNode, 0);
+        todo.emplace_back(0u, 1);
+        uint64_t visited = 0;
+        while (!todo.empty()) {
+            auto [i, depth] = todo.back(); todo.pop_back();
+            if (i >= nNode) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: child index %u out of range", i);
+            if (seen[i]) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: node %u reachable twice (not a tree)", i);
+            seen[i] = 1; ++visited;
+            Info in = info(i);
+            if (in.count > 0) {
+                if (in.count > 16) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: leaf %u holds %d triangles (limit 16)", i, in.count);
+                if (in.ref < 0 || (uint64_t)in.ref + (uint64_t)in.count > nTri) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: leaf %u triangle range out of bounds", i);
+            } else {
+                if (in.count < 0) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: node %u has a negative triangle count", i);
+                if (depth > kMaxStack) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: tree deeper than %d levels", kMaxStack);
+                if (in.ref <= (int)i + 1 || (uint32_t)in.ref >= nNode || i + 1 >= nNode) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: node %u has a bad right child %d", i, in.ref);
+                if (depth > maxInteriorDepth) maxInteriorDepth = depth;
+                todo.emplace_back((uint32_t)in.ref, depth + 1);
+                todo.emplace_back(i + 1, depth + 1);
+            }
+        }
+        (void)visited;
+        // ---- re-lay-out: one 64-byte record per interior node ----
+        auto childRef = [&](uint32_t child) { Info in = info(child); return in.count > 0 ? MakeLeafRef((uint32_t)in.ref, (uint32_t)in.count) : child; };
+        auto copyBox = [&](uint32_t child, float* mn, float* mx) {
+            const float* p = node8 + (size_t)child * 8;
+            for (int k = 0; k < 3; ++k) { mx[k] = p[k]; mn[k] = p[3 + k]; }
+        };
+        for (uint32_t i = 0; i < nNode; ++i) {
+            NodeRec& r = nodes[i];
+            std::memset(&r, 0, sizeof r);
+            Info in = info(i);
+            if (in.count > 0 || !seen[i]) { r.leftRef = r.rightRef = kNoRef; continue; }
+            copyBox(i + 1, r.lmin, r.lmax);
+            copyBox((uint32_t)in.ref, r.rmin, r.rmax);
+            r.leftRef = childRef(i + 1); r.rightRef = childRef((uint32_t)in.ref);
+        }
+    }
+    for (uint32_t i = 0; i < nTri; ++i)
+        if (matIdx[i] < 0 || matIdx[i] >= kMaxMaterials) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: triangle %u uses material slot %d (valid: 0..15)", i, matIdx[i]);
+
+    std::vector<TriRec> tris(nTri);
+    for (uint32_t i = 0; i < nTri; ++i) {
+        const float* p = tri12 + (size_t)i * 12;
+        TriRec& t = tris[i];
+        float v0[3] = {Flush(p[0]), Flush(p[1]), Flush(p[2])};
+        float e1[3], e2[3];
+        for (int k = 0; k < 3; ++k) { e1[k] = Flush(Flush(p[4 + k]) - v0[k]); e2[k] = Flush(Flush(p[8 + k]) - v0[k]); }
+        t.v0[0] = v0[0]; t.v0[1] = v0[1]; t.v0[2] = v0[2];
+        t.e1x = e1[0]; t.e1y = e1[1]; t.e1z = e1[2];
+        t.e2x = e2[0]; t.e2y = e2[1]; t.e2z = e2[2];
+        t.material = matIdx[i]; t.pad[0] = t.pad[1] = 0;
+    }
+
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dNodes) { (void)hipFree(c->dNodes); c->dNodes = nullptr; }
+    if (c->dTris) { (void)hipFree(c->dTris); c->dTris = nullptr; }
+    if (nNode) {
+        HIP_TRY(c, hipMalloc((void**)&c->dNodes, sizeof(NodeRec) * nNode));
+        HIP_TRY(c, hipMemcpy(c->dNodes, nodes.data(), sizeof(NodeRec) * nNode, hipMemcpyHostToDevice));
+    }
+    if (nTri) {
+        HIP_TRY(c, hipMalloc((void**)&c->dTris, sizeof(TriRec) * nTri));
+        HIP_TRY(c, hipMemcpy(c->dTris, tris.data(), sizeof(TriRec) * nTri, hipMemcpyHostToDevice));
+    }
+    SceneParams& sp = c->sp;
+    sp.nodes = c->dNodes; sp.tris = c->dTris; sp.nNode = nNode;
+    if (nNode == 0) sp.rootRef = kNoRef;
+    else {
+        Info in = info(0);
+        sp.rootRef = in.count > 0 ? MakeLeafRef((uint32_t)in.ref, (uint32_t)in.count) : 0u;
+        for (int k = 0; k < 3; ++k) { sp.rootMax[k] = node8[k]; sp.rootMin[k] = node8[3 + k]; }
+    }
+    c->stackEntries = maxInteriorDepth <= 16 ? 16 : (maxInteriorDepth <= 32 ? 32 : 64);
+    c->haveScene = true;
+    return RT_OK;
+}
+
+int rt_set_materials(rt_context* c, const rt_material* m, uint32_t count) {
+    if (!c) return RT_ERR_INVALID;
+    if (count > (uint32_t)kMaxMaterials) return Fail(c, RT_ERR_UNSUPPORTED, "rt_set_materials: %u materials (limit 16)", count);
+    if (count && !m) return Fail(c, RT_ERR_INVALID, "rt_set_materials: NULL table");
+    HIP_TRY(c, hipSetDevice(c->device));
+    MaterialRec recs[kMaxMaterials];
+    std::memset(recs, 0, sizeof recs);
+    for (uint32_t i = 0; i < count; ++i) {
+        for (int k = 0; k < 3; ++k) { recs[i].colour[k] = m[i].colour[k]; recs[i].specular[k] = m[i].specularColour[k]; }
+        recs[i].roughness = m[i].roughness; recs[i].metallic = m[i].metallic; recs[i].transparency = m[i].transparency;
+        recs[i].refractionIndex = m[i].refractionIndex; recs[i].isLight = m[i].isLight ? 1 : 0;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->dMaterials, recs, sizeof recs, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context* c, const rt_camera* cam) {
+    if (!c || !cam) return c ? Fail(c, RT_ERR_INVALID, "rt_set_camera: NULL camera") : RT_ERR_INVALID;
+    for (int k = 0; k < 3; ++k) { c->sp.camPos[k] = cam->position[k]; c->sp.camFacing[k] = cam->facing[k]; }
+    c->sp.vpW = cam->viewportWidth; c->sp.vpD = cam->viewportDistance;
+    return RT_OK;
+}
+
+int rt_set_bounce_limit(rt_context* c, uint32_t bl) {
+    if (!c) return RT_ERR_INVALID;
+    c->sp.bounceLimit = bl;
+    return RT_OK;
+}
+
+int rt_set_noise(rt_context* c, const uint8_t* rgb, uint32_t w, uint32_t h) {
+    if (!c) return RT_ERR_INVALID;
+    if (!rgb || w == 0 || h == 0 || w > 16384 || h > 16384) return Fail(c, RT_ERR_INVALID, "rt_set_noise: bad texture");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint32_t> px((size_t)w * h);
+    for (size_t i = 0; i < px.size(); ++i) px[i] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dNoise) { (void)hipFree(c->dNoise); c->dNoise = nullptr; }
+    HIP_TRY(c, hipMalloc((void**)&c->dNoise, px.size() * 4));
+    HIP_TRY(c, hipMemcpy(c->dNoise, px.data(), px.size() * 4, hipMemcpyHostToDevice));
+    c->sp.noise = c->dNoise; c->sp.noiseW = (int32_t)w; c->sp.noiseH = (int32_t)h;
+    c->haveNoise = true;
+    return RT_OK;
+}
+
+int rt_set_skybox(rt_context* c, const uint8_t* const faces[6], uint32_t size) {
+    if (!c) return RT_ERR_INVALID;
+    if (!faces || size == 0 || size > 8192) return Fail(c, RT_ERR_INVALID, "rt_set_skybox: bad cube map");
+    for (int f = 0; f < 6; ++f) if (!faces[f]) return Fail(c, RT_ERR_INVALID, "rt_set_skybox: face %d is NULL", f);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)size * size;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dSky) { (void)hipFree(c->dSky); c->dSky = nullptr; }
+    HIP_TRY(c, hipMalloc((void**)&c->dSky, n * 6 * 4));
+    for (int f = 0; f < 6; ++f) HIP_TRY(c, hipMemcpy(c->dSky + n * f, faces[f], n * 4, hipMemcpyHostToDevice));
+    c->sp.sky = c->dSky; c->sp.skySize = (int32_t)size;
+    c->haveSky = true;
+    return RT_OK;
+}
+
+int rt_accum_clear(rt_context* c) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->dAccum, 0, (size_t)c->sp.shardTiles * 64 * 16, c->stream));
+    return RT_OK;
+}
+
+int rt_accum_write(rt_context* c, const float* rgba) {
+    if (!c || !rgba) return c ? Fail(c, RT_ERR_INVALID, "rt_accum_write: NULL image") : RT_ERR_INVALID;
+    if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_accum_write: only on an unsharded context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->dLinear, rgba, (size_t)c->width * c->height * 16, hipMemcpyHostToDevice, c->stream));
+    LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, true);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_accum_read(rt_context* c, float* rgba) {
+    if (!c || !rgba) return c ? Fail(c, RT_ERR_INVALID, "rt_accum_read: NULL image") : RT_ERR_INVALID;
+    if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_accum_read: sharded context; gather the shards and call rt_accum_assemble on an unsharded one");
+    HIP_TRY(c, hipSetDevice(c->device));
+    LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, false);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(rgba, c->dLinear, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static int CheckRenderable(rt_context* c, const char* who) {
+    if (!c->haveNoise) return Fail(c, RT_ERR_STATE, "%s: no noise texture (rt_set_noise)", who);
+    if (!c->haveSky) return Fail(c, RT_ERR_STATE, "%s: no skybox (rt_set_skybox)", who);
+    if (!c->haveScene) return Fail(c, RT_ERR_STATE, "%s: no scene (rt_scene_upload)", who);
+    return RT_OK;
+}
+
+static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* seeds3) {
+    std::vector<FrameParams> fr(n);
+    const float BLf = (float)c->sp.bounceLimit;
+    auto hash = [](uint32_t x) { x ^= x >> 17; x *= 0xed5ad4bbU; x ^= x >> 11; x *= 0xac4c1b51U; x ^= x >> 15; x *= 0x31848babU; x ^= x >> 14; return x; };
+    auto hashf = [&](float f) { uint32_t u; std::memcpy(&u, &f, 4); return hash(u); };
+    for (uint32_t k = 0; k < n; ++k) {
+        const float* s = seeds3 + 3 * (size_t)k;
+        FrameParams& f = fr[k];
+        f.frameIndex = first + k;
+        f.seedY = s[1]; f.seedZ = s[2];
+        // Fragment.glsl:392-393, the terms that do not change within a frame
+        f.hashX = hash(0u) + hash(f.frameIndex) + hashf(Flush(Flush(s[0]) * BLf));
+        f.hashY = hash(0u) + hashf(Flush(Flush(s[1]) * BLf));
+        f.weight = 1.0f / (float)(f.frameIndex + 1u);     // Fragment.glsl:487
+    }
+    if (n > c->framesCap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->dFrames) (void)hipFree(c->dFrames);
+        c->dFrames = nullptr; c->framesCap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->dFrames, sizeof(FrameParams) * n));
+        c->framesCap = n;
+    }
+    // pageable source: the copy is staged before the call returns, so `fr` may go out of scope
+    HIP_TRY(c, hipMemcpyAsync(c->dFrames, fr.data(), sizeof(FrameParams) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_render(rt_context* c, uint32_t firstFrameIndex, uint32_t nFrames, const float* seeds3) {
+    if (!c) return RT_ERR_INVALID;
+    if (nFrames == 0) return RT_OK;
+    if (!seeds3) return Fail(c, RT_ERR_INVALID, "rt_render: NULL seeds");
+    int rc = CheckRenderable(c, "rt_render");
+    if (rc != RT_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = UploadFrames(c, firstFrameIndex, nFrames, seeds3);
+    if (rc != RT_OK) return rc;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
+    else { HIP_TRY(c, hipEventCreate(&ev.first)); HIP_TRY(c, hipEventCreate(&ev.second)); }
+    HIP_TRY(c, hipEventRecord(ev.first, c->stream));
+    LaunchTrace(c->stackEntries, c->countAll, false, c->stream, c->sp.shardTiles, c->sp, c->dFrames, nFrames, c->dAccum, c->dTally, nullptr);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(ev.second, c->stream));
+    c->pendingEvents.push_back(ev);
+    if (!c->countAll) {
+        // pixels of this shard: tiles j*world+rank, clipped to the image
+        uint64_t px = 0;
+        const uint32_t nTiles = c->sp.tilesX * c->sp.tilesY;
+        for (uint32_t t = c->sp.shardRank; t < nTiles; t += c->sp.shardWorld) {
+            uint32_t tx = t % c->sp.tilesX, ty = t / c->sp.tilesX;
+            uint32_t w = std::min<uint32_t>(kTile, c->width - tx * kTile), h = std::min<uint32_t>(kTile, c->height - ty * kTile);
+            px += (uint64_t)w * h;
+        }
+        c->hostPaths += px * nFrames;
+    }
+    if (c->pendingEvents.size() > 256) { rc = ResolveEvents(c); if (rc != RT_OK) return rc; }
+    return RT_OK;
+}
+
+int rt_sync(rt_context* c) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) {
+    if (!c || !seed3 || !out3) return c ? Fail(c, RT_ERR_INVALID, "rt_primary_ids: NULL argument") : RT_ERR_INVALID;
+    if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_primary_ids: only on an unsharded context");
+    int rc = CheckRenderable(c, "rt_primary_ids");
+    if (rc != RT_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = UploadFrames(c, 0, 1, seed3);
+    if (rc != RT_OK) return rc;
+    const size_t n = (size_t)c->sp.shardTiles * 64;
+    if (!c->dIds) HIP_TRY(c, hipMalloc((void**)&c->dIds, n * 3 * sizeof(int32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->dIds, 0xff, n * 3 * sizeof(int32_t), c->stream));
+    LaunchTrace(c->stackEntries, true, true, c->stream, c->sp.shardTiles, c->sp, c->dFrames, 1, c->dAccum, c->dTally, c->dIds);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<int32_t> tiled(n * 3);
+    HIP_TRY(c, hipMemcpyAsync(tiled.data(), c->dIds, n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t y = 0; y < c->height; ++y)
+        for (uint32_t x = 0; x < c->width; ++x) {
+            size_t slot = ((size_t)(y / kTile) * c->sp.tilesX + x / kTile) * 64 + (y % kTile) * kTile + x % kTile;
+            std::memcpy(out3 + ((size_t)y * c->width + x) * 3, tiled.data() + slot * 3, 3 * sizeof(int32_t));
+        }
+    // the id pass also ran the tallies; drop them so that counters describe rt_render only
+    HIP_TRY(c, hipMemsetAsync(c->dTally, 0, (size_t)kCounterSlots * c->sp.shardTiles * sizeof(uint32_t), c->stream));
+    return RT_OK;
+}
+
+int rt_postprocess(rt_context* c, int bloom_on, float* rgba_out, uint8_t* rgb8_out) {
+    if (!c) return RT_ERR_INVALID;
+    if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_postprocess: only on an unsharded context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, false);
+    HIP_TRY(c, hipGetLastError());
+    std::string err;
+    int rc = RunPostprocess(c->stream, c->dLinear, c->width, c->height, bloom_on, &c->postScratch, rgba_out, rgb8_out, err);
+    if (rc != RT_OK) return Fail(c, rc, "rt_postprocess: %s", err.c_str());
+    return RT_OK;
+}
+
+int rt_get_counters(rt_context* c, rt_counters* out, int reset) {
+    if (!c || !out) return c ? Fail(c, RT_ERR_INVALID, "rt_get_counters: NULL out") : RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    LaunchReduceTally(c->stream, c->dTally, c->sp.shardTiles, c->dTotals, kCounterSlots);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long t[kCounterSlots];
+    HIP_TRY(c, hipMemcpyAsync(t, c->dTotals, sizeof t, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->rays = t[kRays]; out->node_pops = t[kPops]; out->boxes_tested = t[kBoxes]; out->tris_tested = t[kTris];
+    out->noise_fetches = t[kNoise]; out->sky_fetches = t[kSky]; out->paths = t[kPaths] + c->hostPaths;
+    if (reset) c->hostPaths = 0;
+    if (reset) HIP_TRY(c, hipMemsetAsync(c->dTotals, 0, sizeof t, c->stream));
+    return RT_OK;
+}
+
+int rt_set_shard(rt_context* c, uint32_t rank, uint32_t world) {
+    if (!c) return RT_ERR_INVALID;
+    if (world == 0 || rank >= world) return Fail(c, RT_ERR_INVALID, "rt_set_shard: rank %u of %u", rank, world);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->sp.shardRank = rank; c->sp.shardWorld = world;
+    return AllocShard(c);
+}
+
+int rt_shard_tiles(const rt_context* c, uint32_t* tilesPerRank) {
+    if (!c || !tilesPerRank) return RT_ERR_INVALID;
+    *tilesPerRank = c->sp.shardTiles;
+    return RT_OK;
+}
+
+int rt_shard_device_ptr(rt_context* c, void** p) {
+    if (!c || !p) return RT_ERR_INVALID;
+    *p = c->dAccum;
+    return RT_OK;
+}
+
+int rt_accum_assemble(rt_context* c, const void* gatheredDevice, uint32_t world) {
+    if (!c || !gatheredDevice || world == 0) return c ? Fail(c, RT_ERR_INVALID, "rt_accum_assemble: bad argument") : RT_ERR_INVALID;
+    if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_accum_assemble: the assembling context must be unsharded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t nTiles = c->sp.tilesX * c->sp.tilesY, per = (nTiles + world - 1) / world;
+    LaunchUntile(c->stream, gatheredDevice, c->dLinear, c->width, c->height, c->sp.tilesX, world, per, false);
+    LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, true);
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_set_stream(rt_context* c, void* hipStream) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hipStream ? (hipStream_t)hipStream : c->ownStream;
+    return RT_OK;
+}
+
+int rt_kernel_time(rt_context* c, double* ms_total, uint64_t* launches, int reset) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ResolveEvents(c);
+    if (rc != RT_OK) return rc;
+    if (ms_total) *ms_total = c->kernelMs;
+    if (launches) *launches = c->kernelLaunches;
+    if (reset) { c->kernelMs = 0.0; c->kernelLaunches = 0; }
+    return RT_OK;
+}
+
+int rt_set_counting(rt_context* c, int on) {
+    if (!c) return RT_ERR_INVALID;
+    c->countAll = on != 0;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,473 @@
+// Path-tracing kernels for gfx950 (MI355X): one wave64 per 8x8 pixel tile, one lane per pixel.
+//
+// What is computed is the reference's tracer pass (src/shaders/Fragment.glsl of the reference,
+// cited below as F:<line>), with every floating-point operation in the same order and rounding
+// as that shader evaluates it under Mesa llvmpipe: reversed three-term dot products, normalize as
+// multiply by 1/sqrt, mix as a + t*(b-a), IEEE division and square root, denormals flushed, and
+// llvmpipe's 8-bit fixed-point bilinear texture filter. This file must be compiled with
+// -ffp-contract=off -fgpu-flush-denormals-to-zero (see Makefile); results are then bit-identical
+// to the CPU parity oracle.
+//
+// How it is computed is specific to this hardware:
+//   * BVH: 64-byte records hold both children of an interior node, leaves are encoded in the
+//     child reference, so a visit is one aligned 64 B fetch instead of three 32 B fetches and the
+//     second AABB test the shader performs when it pops a node is replaced by the entry distance
+//     remembered from when it was pushed (same value, same comparison).
+//   * The near child is descended into directly; only the far child goes to the stack, which lives
+//     in LDS as [entry][lane] (conflict-free: each lane owns a column) with 8-byte entries.
+//   * Lanes are persistent over frames: a lane that finishes its path starts the next frame's
+//     path for its pixel at once while its neighbours are still bouncing, and the running mean
+//     stays in registers; the accumulation image is read and written once per launch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+using namespace rtd;
+
+namespace {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// GLSL built-ins as llvmpipe lowers them
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3 normalize3(V3 v) { float r = 1.0f / sqrtf(dot3(v, v)); return v * r; }
+__device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ V3 reflect3(V3 I, V3 N) { float d = dot3(N, I); return I - (2.0f * d) * N; }
+__device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
+    float d = dot3(N, I);
+    float k = 1.0f - eta * (eta * (1.0f - d * d));
+    if (k < 0.0f) return mk(0.0f, 0.0f, 0.0f);
+    return eta * I - (eta * d + sqrtf(k)) * N;
+}
+__device__ __forceinline__ V3 abs3(V3 a) { return mk(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+
+__device__ __forceinline__ uint32_t Hash(uint32_t x) {      // F:96-105
+    x ^= x >> 17; x *= 0xed5ad4bbU; x ^= x >> 11; x *= 0xac4c1b51U; x ^= x >> 15; x *= 0x31848babU; x ^= x >> 14;
+    return x;
+}
+__device__ __forceinline__ uint32_t Hashf(float f) { return Hash(__float_as_uint(f)); }
+
+// ---- llvmpipe's default LINEAR filter on 8-bit formats: 8.8 fixed-point coordinates, rounded
+// 8-bit lerps, x first then y, result scaled by 1/255 ----
+__device__ __forceinline__ int lerp8(int a, int b, int w) { return (a + (((b - a) * w + 128) >> 8)) & 255; }
+
+__device__ __forceinline__ uint32_t bilerp_rgbx(uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, int wx, int wy, int ch) {
+    int sh = ch * 8;
+    int a = (t00 >> sh) & 255, b = (t10 >> sh) & 255, c = (t01 >> sh) & 255, d = (t11 >> sh) & 255;
+    return (uint32_t)lerp8(lerp8(a, b, wx), lerp8(c, d, wx), wy);
+}
+
+__device__ __forceinline__ void coord_repeat(float c, int n, int& i0, int& i1, int& w) {
+    float f = c - floorf(c);
+    f = f * (float)n;
+    f = f * 256.0f;
+    int fixed = (int)rintf(f) - 128;
+    w = fixed & 255;
+    i0 = fixed >> 8;
+    if (i0 < 0) i0 = n - 1;
+    if (i0 > n - 1) i0 = n - 1;
+    i1 = (i0 == n - 1) ? 0 : i0 + 1;
+}
+
+__device__ __forceinline__ V3 sample_noise(const SceneParams& sp, float s, float t) {   // texture(u_RgbNoise, ..)
+    int x0, x1, wx, y0, y1, wy;
+    coord_repeat(s, sp.noiseW, x0, x1, wx);
+    coord_repeat(t, sp.noiseH, y0, y1, wy);
+    const uint32_t* T = sp.noise;
+    uint32_t t00 = T[y0 * sp.noiseW + x0], t10 = T[y0 * sp.noiseW + x1];
+    uint32_t t01 = T[y1 * sp.noiseW + x0], t11 = T[y1 * sp.noiseW + x1];
+    const float k = (float)(1.0 / 255.0);
+    return mk((float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 0) * k, (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 1) * k,
+              (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 2) * k);
+}
+
+__device__ __forceinline__ void coord_clamp(float c, int n, int& i0, int& i1, int& w) {
+    float f = c * (float)n;
+    f = f * 256.0f;
+    int fixed = (int)rintf(f) - 128;
+    w = fixed & 255;
+    i0 = fixed >> 8;
+    i1 = i0 + 1;
+    i0 = min(max(i0, 0), n - 1);
+    i1 = min(max(i1, 0), n - 1);
+}
+
+// texture(u_Skybox, RotateAroundAxis(dir, (1,0,0), -3.1415/2)) : F:158-163,406,411
+__device__ __forceinline__ V3 sample_sky(const SceneParams& sp, V3 dir) {
+    const V3 k = mk(1.0f, 0.0f, 0.0f);
+    V3 d = (dir * sp.skyCos + cross3(k, dir) * sp.skySin) + (k * dot3(k, dir)) * (1.0f - sp.skyCos);
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int axis = (az >= fmaxf(ax, ay)) ? 2 : (ax > ay ? 0 : 1);
+    float ma = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+    bool neg = (__float_as_uint(ma) >> 31) != 0;
+    float sc, tc;
+    if (axis == 0) { sc = neg ? d.z : -d.z; tc = -d.y; }
+    else if (axis == 1) { sc = d.x; tc = neg ? -d.z : d.z; }
+    else { sc = neg ? -d.x : d.x; tc = -d.y; }
+    float ima = 0.5f / fabsf(ma);
+    float s = sc * ima + 0.5f, t = tc * ima + 0.5f;
+    int x0, x1, wx, y0, y1, wy;
+    const int S = sp.skySize;
+    coord_clamp(s, S, x0, x1, wx);
+    coord_clamp(t, S, y0, y1, wy);
+    const uint32_t* T = sp.sky + (size_t)(axis * 2 + (neg ? 1 : 0)) * S * S;
+    uint32_t t00 = T[y0 * S + x0], t10 = T[y0 * S + x1], t01 = T[y1 * S + x0], t11 = T[y1 * S + x1];
+    const float kk = (float)(1.0 / 255.0);
+    return mk((float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 0) * kk, (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 1) * kk,
+              (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 2) * kk);
+}
+
+struct Ray { V3 o, d, inv; };
+__device__ __forceinline__ Ray MakeRay(V3 o, V3 d) {            // F:135-142 (magnitude is always 1)
+    Ray r; r.o = o; r.d = d; r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); return r;
+}
+
+// F:242-263. Returns hit flag, entry distance in tmin.
+__device__ __forceinline__ bool hit_box(const Ray& r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float& tmin) {
+    float t0x = (mnx - r.o.x) * r.inv.x, t0y = (mny - r.o.y) * r.inv.y, t0z = (mnz - r.o.z) * r.inv.z;
+    float t1x = (mxx - r.o.x) * r.inv.x, t1y = (mxy - r.o.y) * r.inv.y, t1z = (mxz - r.o.z) * r.inv.z;
+    float lo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float hi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    tmin = lo;
+    return hi >= fmaxf(lo, 0.0f);
+}
+
+struct Hit { float t; int index; };
+
+struct Tally { uint32_t rays, pops, boxes, tris, noise, sky, paths; };
+
+// Closest-hit traversal, F:265-326. STACK = LDS entries per lane (>= depth of the deepest interior node).
+template <int STACK, bool COUNT>
+__device__ __forceinline__ void traverse(const SceneParams& sp, const Ray& ray, uint2* __restrict__ stack /* this lane's column */,
+                                         Hit& best, int& iterations, Tally& tl) {
+    best.t = INFINITY; best.index = -1;
+    int iters = 0;
+    int top = 0;                       // number of deferred entries of this lane
+    uint32_t cur = kNoRef;
+    if (sp.rootRef != kNoRef) {
+        iters = 1;
+        float tr;
+        if (COUNT) tl.boxes++;
+        if (hit_box(ray, sp.rootMin[0], sp.rootMin[1], sp.rootMin[2], sp.rootMax[0], sp.rootMax[1], sp.rootMax[2], tr) && !(tr >= best.t))
+            cur = sp.rootRef;
+    }
+    for (;;) {
+        if (cur == kNoRef) {
+            // pop: F:277-283 with the entry distance remembered from push time
+            if (top == 0) break;
+            --top;
+            uint2 e = stack[top * 64];
+            iters++;
+            if (__uint_as_float(e.y) >= best.t) continue;
+            cur = e.x;
+        }
+        if (cur & kLeafBit) {
+            // leaf: F:285-295, triangles in order, strictly closer wins
+            uint32_t first = cur & 0x07ffffffu, count = ((cur >> 27) & 15u) + 1u;
+            for (uint32_t i = first; i < first + count; ++i) {
+                const float4* T = reinterpret_cast<const float4*>(sp.tris + i);
+                float4 a = T[0], b = T[1], c = T[2];
+                if (COUNT) tl.tris++;
+                V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
+                V3 h = cross3(ray.d, e2);                       // F:207-240
+                float det = dot3(e1, h);
+                if (fabsf(det) < 1e-8f) continue;
+                float invDet = 1.0f / det;
+                V3 s = ray.o - v0;
+                float u = invDet * dot3(s, h);
+                if (u < 0.0f || u > 1.0f) continue;
+                V3 q = cross3(s, e1);
+                float v = invDet * dot3(ray.d, q);
+                if (v < 0.0f || u + v > 1.0f) continue;
+                float t = invDet * dot3(e2, q);
+                if (t < 0.0001f) continue;
+                if (best.t > t) { best.t = t; best.index = (int)i; }
+            }
+            cur = kNoRef;
+        } else {
+            // interior: both children from one 64-byte record, F:296-311
+            const float4* N = reinterpret_cast<const float4*>(sp.nodes + cur);
+            float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+            if (COUNT) tl.boxes += 2;
+            float tL, tR;
+            bool hL = hit_box(ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tL);
+            bool hR = hit_box(ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tR);
+            uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
+            bool okL = hL && tL < best.t, okR = hR && tR < best.t;
+            // the child pushed last is popped next; `tL < tR` decides which one that is
+            bool leftFirst = tL < tR;
+            uint32_t nearRef = leftFirst ? refL : refR, farRef = leftFirst ? refR : refL;
+            float nearT = leftFirst ? tL : tR, farT = leftFirst ? tR : tL;
+            bool okNear = leftFirst ? okL : okR, okFar = leftFirst ? okR : okL;
+            (void)nearT;
+            if (okNear) {
+                if (okFar) { stack[top * 64] = make_uint2(farRef, __float_as_uint(farT)); ++top; }
+                iters++;               // the immediate pop of the near child (its test passes: best.t is unchanged)
+                cur = nearRef;
+            } else if (okFar) {
+                iters++;
+                cur = farRef;
+            } else {
+                cur = kNoRef;
+            }
+        }
+    }
+    iterations = iters;
+    if (COUNT) { tl.pops += (uint32_t)iters; }
+    tl.rays++;
+}
+
+// Per-lane path state carried across traversals.
+struct Path {
+    Ray ray;
+    V3 throughput;      // rayColour
+    int bounce;         // i
+};
+
+template <int STACK, bool COUNT, bool IDS>
+__global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
+                                                   float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][shardTiles] */,
+                                                   int32_t* __restrict__ ids /* IDS only: [tile*64+lane][3] */, uint32_t nBlocks) {
+    __shared__ uint2 lds_stack[STACK * 64];
+    const uint32_t lane = threadIdx.x;
+    // XCD-aware tile order: consecutive blocks go round-robin over the 8 XCDs, so give each XCD
+    // a contiguous band of tiles (neighbouring tiles walk the same BVH subtrees -> shared L2).
+    uint32_t b = blockIdx.x;
+    {
+        const uint32_t q = nBlocks / 8u, r = nBlocks % 8u, xcd = b % 8u;
+        b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+    }
+    const uint32_t localTile = b;
+    const uint32_t tile = localTile * sp.shardWorld + sp.shardRank;
+    const uint32_t nTiles = sp.tilesX * sp.tilesY;
+    const uint32_t tx = tile % sp.tilesX, ty = tile / sp.tilesX;
+    const uint32_t px = tx * kTile + (lane & 7u), py = ty * kTile + (lane >> 3);
+    const bool valid = tile < nTiles && px < sp.width && py < sp.height;
+    uint2* stack = lds_stack + lane;
+    const size_t slot = (size_t)localTile * 64 + lane;
+
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    if (valid) {
+        const uint32_t BL = sp.bounceLimit;
+        const V3 camPos = mk(sp.camPos[0], sp.camPos[1], sp.camPos[2]);
+        const V3 facing = mk(sp.camFacing[0], sp.camFacing[1], sp.camFacing[2]);
+        const float resx = (float)sp.width, resy = (float)sp.height;
+        const float nresx = (float)sp.noiseW, nresy = (float)sp.noiseH;
+        // F:144-148
+        const float vpH = sp.vpW * (resy / resx);
+        const V3 U = normalize3(cross3(facing, mk(0.0f, 0.0f, 1.0f)));
+        const V3 Vd = normalize3(cross3(U, facing));
+        const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+
+        float4 acc = IDS ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[slot];
+        V3 previous = mk(acc.x, acc.y, acc.z);
+        uint32_t k = 0;                 // frame counter of this lane
+        FrameParams fp = frames[0];
+        Path p;
+        bool fresh = true;              // start a new path before the next traversal
+        uint32_t segments = 0;          // traversals of the current path (bounded by kMaxSegments)
+        V3 hitNormal = mk(0.0f, 0.0f, 0.0f);   // hitRecord.normal persists across bounces (F:381)
+        V3 hitColour = mk(0.0f, 0.0f, 0.0f);   // hitRecord.material.colour likewise
+        for (;;) {
+            if (fresh) {
+                // F:461-462: per-frame jitter from the noise texture, primary ray
+                if (COUNT) tl.noise++;
+                V3 ro = sample_noise(sp, fp.seedY + 0.007f * 0.0f, fp.seedZ + 0.007f * 0.0f);
+                V3 pt = ((camPos + sp.vpD * facing) + (sp.vpW * (-0.5f + ((fx - 0.5f) + ro.x) / resx)) * U) +
+                        (vpH * (-0.5f + ((fy - 0.5f) + ro.y) / resy)) * Vd;
+                p.ray = MakeRay(camPos, normalize3(pt - camPos));
+                p.throughput = mk(1.0f, 1.0f, 1.0f);
+                p.bounce = 0;
+                segments = 0;
+                hitNormal = mk(0.0f, 0.0f, 0.0f);      // a new invocation starts with a blank hit record
+                hitColour = mk(0.0f, 0.0f, 0.0f);
+                fresh = false;
+            }
+            Hit hit; int iters;
+            traverse<STACK, COUNT>(sp, p.ray, stack, hit, iters, tl);
+            if (IDS) {
+                ids[slot * 3 + 0] = hit.index; ids[slot * 3 + 1] = (int32_t)__float_as_uint(hit.t); ids[slot * 3 + 2] = iters;
+                break;
+            }
+            const bool hitAnything = hit.index >= 0;
+            V3 hitPoint = mk(0.0f, 0.0f, 0.0f);
+            bool frontFace = false;
+            MaterialRec m;
+            if (hitAnything) {
+                // the part of hitTriangle that only the accepted hit needs (F:235-238) + material (F:291)
+                const float4* T = reinterpret_cast<const float4*>(sp.tris + hit.index);
+                float4 a = T[0], b4 = T[1], c = T[2];
+                V3 e1 = mk(a.w, b4.x, b4.y), e2 = mk(b4.z, b4.w, c.x);
+                hitPoint = p.ray.o + (1.0f * hit.t) * p.ray.d;
+                V3 n = normalize3(cross3(e1, e2));
+                frontFace = dot3(p.ray.d, n) < 0.0f;
+                hitNormal = frontFace ? n : -n;
+                m = sp.materials[__float_as_int(c.y)];
+                hitColour = mk(m.colour[0], m.colour[1], m.colour[2]);
+            }
+            bool done = false;          // path finished with colour `result`
+            V3 result = mk(0.0f, 0.0f, 0.0f);
+            if (BL == 0u) {
+                // BVH heat map, F:313-324,386-387
+                const float itf = (float)iters;
+                if (iters < 64) { float g = (1.0f / 64.0f) * itf; result = mk(g, g, g); }
+                else if (iters < 128) { float kk = (float)(iters - 64); result = mk(1.0f - (0.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk); }
+                else { float kk = (float)(iters - 128); result = mk(1.0f - (1.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk); }
+                done = true;
+            } else if (BL == 1u) {
+                result = abs3(hitNormal);                       // F:388-389
+                done = true;
+            } else {
+                const int i = p.bounce;
+                // F:391-394
+                uint32_t sx = Hashf(p.ray.o.x + p.ray.d.y) + Hash((uint32_t)i) + fp.hashX;
+                uint32_t sy = Hashf(p.ray.o.y + p.ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
+                float fsx = (float)sx, fsy = (float)sy;
+                float seedx = (fsx - nresx * floorf(fsx / nresx)) / nresx;
+                float seedy = (fsy - nresy * floorf(fsy / nresy)) / nresy;
+                if (!hitAnything) {
+                    if (COUNT) tl.sky += (i == 0) ? 2u : 1u;
+                    result = p.throughput * sample_sky(sp, p.ray.d);     // F:410-413
+                    done = true;
+                } else if (m.isLight) {
+                    result = (p.throughput * hitColour) * m.transparency;   // F:415-418
+                    done = true;
+                } else {
+                    V3 next;
+                    int ii = i;
+                    if (COUNT) tl.noise++;
+                    float trRng = sample_noise(sp, seedx + 0.01534f, seedy + 0.183f).x;   // F:420
+                    if (trRng < m.transparency) {
+                        // TransparentScatter, F:328-336
+                        const float AIR = 1.0003f;
+                        float ri = frontFace ? AIR / m.refractionIndex : m.refractionIndex / AIR;
+                        float cos_theta = fminf(dot3(-p.ray.d, hitNormal), 1.0f);
+                        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                        next = (ri * sin_theta <= 1.0f) ? refract3(p.ray.d, hitNormal, ri) : reflect3(p.ray.d, hitNormal);
+                        if (trRng < 0.5f) ii--;
+                    } else {
+                        if (COUNT) tl.noise += 2;
+                        V3 n3 = sample_noise(sp, seedx - 0.062f, seedy - 0.0345f);       // F:426
+                        V3 diffuseDir = normalize3(hitNormal + ((2.0f * n3) - mk(1.0f, 1.0f, 1.0f)) * m.roughness);
+                        V3 specularDir = reflect3(p.ray.d, hitNormal);
+                        bool isSpecular = sample_noise(sp, seedx, seedy).y < (1.0f - m.roughness);   // F:428
+                        specularDir = mix3(specularDir, diffuseDir, m.roughness);
+                        next = isSpecular ? specularDir : diffuseDir;
+                        V3 spec = mk(m.specular[0], m.specular[1], m.specular[2]);
+                        p.throughput = p.throughput * (isSpecular ? mix3(spec, hitColour, m.metallic) : hitColour);
+                    }
+                    p.ray = MakeRay(hitPoint + 1e-4f * next, next);         // F:433
+                    // adaptive early-out against the accumulated pixel, F:435-446
+                    V3 diff = abs3(p.throughput - previous);
+                    float distance = (diff.x + diff.y) + diff.z;
+                    int inc = (int)(BL / 4u);
+                    if (distance < 1.0f) ii += inc;
+                    if (distance < 0.4f) ii += inc;
+                    if (distance < 0.2f) ii += inc;
+                    ii++;                                                   // ++i of the for statement
+                    p.bounce = ii;
+                    ++segments;
+                    // F:384,448; plus a bound on free glass bounces so that every wave is sure to finish
+                    if (!((uint32_t)ii <= BL) || segments >= kMaxSegments) { result = mk(0.0f, 0.0f, 0.0f); done = true; }
+                }
+            }
+            if (done) {
+                // F:480-487
+                V3 rgb = mk(0.0f, 0.0f, 0.0f) + result;
+                rgb = rgb * (1.0f / 1.0f);
+                previous = mix3(previous, rgb, fp.weight);
+                tl.paths++;
+                ++k;
+                if (k >= nFrames) break;
+                fp = frames[k];
+                fresh = true;
+            }
+        }
+        if (!IDS) accum[slot] = make_float4(previous.x, previous.y, previous.z, 0.0f);
+    }
+
+    // per-tile tallies: the owning wave adds its sums (no atomics; one wave owns a tile)
+    uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths};
+    const int nSlots = COUNT ? (int)kCounterSlots : 1;
+    for (int s = 0; s < nSlots; ++s) {
+        uint32_t v = (s == 0 || COUNT) ? vals[s] : 0u;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && tile < nTiles) tally[(size_t)s * sp.shardTiles + localTile] += v;
+    }
+}
+
+// Sums the per-tile tallies into 64-bit totals: out[slot] += sum(tally[slot][*]); clears tally.
+__global__ void reduce_tally_kernel(uint32_t* __restrict__ tally, uint32_t nTiles, unsigned long long* __restrict__ out) {
+    const int slot = blockIdx.x;
+    unsigned long long s = 0;
+    for (uint32_t i = threadIdx.x; i < nTiles; i += blockDim.x) {
+        s += tally[(size_t)slot * nTiles + i];
+        tally[(size_t)slot * nTiles + i] = 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ unsigned long long part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) t += part[w];
+        out[slot] += t;
+    }
+}
+
+// Tile-major <-> row-major conversion of the accumulation image.
+__global__ void untile_kernel(const float4* __restrict__ tiled, float4* __restrict__ linear, uint32_t width, uint32_t height,
+                              uint32_t tilesX, uint32_t world, uint32_t shardTiles, int toTiled) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width || y >= height) return;
+    uint32_t tile = (y / kTile) * tilesX + x / kTile, lane = (y % kTile) * kTile + x % kTile;
+    // gathered layout: rank-major, then local tile
+    size_t slot = ((size_t)(tile % world) * shardTiles + tile / world) * 64 + lane;
+    if (toTiled) const_cast<float4*>(tiled)[slot] = linear[(size_t)y * width + x];
+    else linear[(size_t)y * width + x] = tiled[slot];
+}
+
+}  // namespace
+
+// ---- launchers used by rt_api.cpp ----
+namespace rtd {
+
+template <int STACK>
+static void launch_stack(bool count, bool ids, hipStream_t st, uint32_t nBlocks, const SceneParams& sp, const FrameParams* frames,
+                         uint32_t nFrames, float4* accum, uint32_t* tally, int32_t* idsOut) {
+    dim3 grid(nBlocks), block(64);
+    if (ids) hipLaunchKernelGGL((trace_kernel<STACK, true, true>), grid, block, 0, st, sp, frames, nFrames, accum, tally, idsOut, nBlocks);
+    else if (count) hipLaunchKernelGGL((trace_kernel<STACK, true, false>), grid, block, 0, st, sp, frames, nFrames, accum, tally, idsOut, nBlocks);
+    else hipLaunchKernelGGL((trace_kernel<STACK, false, false>), grid, block, 0, st, sp, frames, nFrames, accum, tally, idsOut, nBlocks);
+}
+
+// stackEntries must be 16, 32 or 64.
+void LaunchTrace(int stackEntries, bool count, bool ids, hipStream_t st, uint32_t nBlocks, const SceneParams& sp, const FrameParams* frames,
+                 uint32_t nFrames, void* accum, uint32_t* tally, int32_t* idsOut) {
+    float4* a = static_cast<float4*>(accum);
+    if (stackEntries <= 16) launch_stack<16>(count, ids, st, nBlocks, sp, frames, nFrames, a, tally, idsOut);
+    else if (stackEntries <= 32) launch_stack<32>(count, ids, st, nBlocks, sp, frames, nFrames, a, tally, idsOut);
+    else launch_stack<64>(count, ids, st, nBlocks, sp, frames, nFrames, a, tally, idsOut);
+}
+
+void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots) {
+    hipLaunchKernelGGL(reduce_tally_kernel, dim3(slots), dim3(256), 0, st, tally, nTiles, out);
+}
+
+void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t width, uint32_t height, uint32_t tilesX, uint32_t world,
+                  uint32_t shardTiles, bool toTiled) {
+    dim3 block(32, 8), grid((width + 31) / 32, (height + 7) / 8);
+    hipLaunchKernelGGL(untile_kernel, grid, block, 0, st, static_cast<const float4*>(tiled), static_cast<float4*>(linear), width, height,
+                       tilesX, world, shardTiles, toTiled ? 1 : 0);
+}
+
+}  // namespace rtd
