@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+Metric (BASELINE.json): Mrays/s (whole node), Sponza 3840x2160, 8 bounces; ms/frame at 1 spp.
+A "step" is one progressive frame (1 sample per pixel) of the whole image. A ray is one BVH
+traversal (primary or bounce segment), counted exactly on the device.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: image tiles (8x8 pixels) are dealt round-robin over the ranks, every rank holds the whole
+scene, and each step ends with an RCCL gather of the ranks' accumulation shards to rank 0
+(framebuffer only). Total work is fixed as N grows -> "scaling": "strong".
+
+The scene is a deterministic synthetic stand-in (the reference's Sponza.off is a Git-LFS stub),
+written to and loaded from the reference's own .off/.txt formats.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracing_amd as ra  # noqa: E402
+from raytracing_amd import scenes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, 8 TB/s
+
+WORKLOADS = {
+    # name: (scene generator, kwargs, width, height, bounce limit)
+    "sponza_like_3840x2160_b8": ("sponza_like", {"target_tris": 260_000}, 3840, 2160, 8),
+    "teapot_like_1920x1080_b8": ("teapot_like", {"target_tris": 140_000}, 1920, 1080, 8),
+    "dragon_like_1920x1080_b16": ("dragon_like", {"target_tris": 870_000}, 1920, 1080, 16),
+    "lightbox_640x360_b4": ("lightbox", {}, 640, 360, 4),
+}
+
+
+def algorithmic_bytes(c):
+    """Algorithmic bytes moved by the work the counters describe: 32 B per distinct box tested,
+    48 B per triangle tested, 4 B material index per hit, 12 B per noise fetch (4 RGB8 texels),
+    16 B per sky fetch (4 RGBA8 texels), 32 B framebuffer traffic per pixel sample."""
+    return (32 * c["boxes_tested"] + 48 * c["tris_tested"] + 4 * c["hits"] + 12 * c["noise_fetches"] +
+            16 * c["sky_fetches"] + 32 * c["paths"])
+
+
+def load_workload(name, threads):
+    gen, kw, W, H, bl = WORKLOADS[name]
+    cache = os.path.join(tempfile.gettempdir(), "rt_bench_" + name)
+    paths_file = os.path.join(cache, "paths.json")
+    if not os.path.exists(paths_file):
+        paths = scenes.write_objects(scenes.SCENES[gen](**kw), cache + ".tmp%d" % os.getpid())
+        os.makedirs(cache, exist_ok=True)
+        final = []
+        for p in paths:
+            q = os.path.join(cache, os.path.basename(p))
+            os.replace(p, q)
+            final.append(q)
+        with open(paths_file, "w") as f:
+            json.dump(final, f)
+    with open(paths_file) as f:
+        paths = json.load(f)
+    return ra.load_scene(paths, build_threads=threads), W, H, bl
+
+
+def setup(r, sc, noise, sky, bl):
+    r.set_scene_data(sc)
+    fov = np.float32(120 * 0.01745329251994329576923690768489)
+    r.set_camera((0, 0, 0), (1, 0, 0), float(fov), float(np.float32(2.0 * np.tan(float(fov) / 2.0))))
+    r.set_noise(noise)
+    r.set_skybox(sky)
+    r.set_bounce_limit(bl)
+
+
+def cpu_baseline(sc, noise, sky, bl, W, H):
+    """The CPU restatement (oracle) timed on this host's cores on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from rt_oracle import Oracle
+    cores = min(16, os.cpu_count() or 1)
+    w, h, frames = W // 4, H // 4, 2
+    o = Oracle(w, h, threads=cores)
+    o.set_scene(sc.tri12, sc.matidx, sc.node8)
+    o.set_materials(sc.materials[:16])
+    fov = np.float32(120 * 0.01745329251994329576923690768489)
+    o.set_camera((0, 0, 0), (1, 0, 0), float(fov), float(np.float32(2.0 * np.tan(float(fov) / 2.0))))
+    o.set_noise(noise)
+    o.set_skybox(sky)
+    o.set_bounce_limit(bl)
+    seeds = scenes.frame_seeds(frames)
+    o.counters(reset=True)
+    t0 = time.perf_counter()
+    o.render(0, seeds)
+    dt = time.perf_counter() - t0
+    rays = o.counters()["rays"]
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "same scene, camera and bounce limit at %dx%d, %d frames (%d rays, %.1f s)" % (w, h, frames, rays, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sponza_like_3840x2160_b8", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented replay that measures algorithmic bytes")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    K, Wm = args.steps, args.warmup
+    sc, W, H, bl = load_workload(args.workload, threads=min(16, os.cpu_count() or 1))
+    noise, sky = scenes.noise_texture(), scenes.sky_cubemap()
+    seeds = scenes.frame_seeds(Wm + K)
+
+    r = ra.Renderer(W, H, device=local_rank)
+    setup(r, sc, noise, sky, bl)
+    root = None
+    shard = gathered = None
+    if world > 1:
+        r.set_shard(rank, world)
+        per = r.shard_tiles()
+        # torch tensors are only plumbing: device memory for the gather's send/receive sides
+        shard = torch.empty(per * 64 * 4, dtype=torch.float32, device="cuda")
+        if rank == 0:
+            flat = torch.empty(world * shard.numel(), dtype=torch.float32, device="cuda")
+            gathered = list(flat.chunk(world))              # the gather writes the shards back to back
+            root = ra.Renderer(W, H, device=local_rank)     # unsharded context that assembles the image
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpyDtoDAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+
+    def step(k):
+        r.render(k, seeds[k:k + 1])
+        if world > 1:
+            r.sync()
+            # shard -> send buffer (device-to-device), gather to rank 0 over RCCL/xGMI
+            hip.hipMemcpyDtoDAsync(shard.data_ptr(), r.shard_device_ptr(), shard.numel() * 4, None)
+            dist.gather(shard, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                torch.cuda.synchronize()
+                root.assemble(flat.data_ptr(), world)
+
+    def fence():
+        r.sync()
+        if root is not None:
+            root.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for k in range(Wm):
+        step(k)
+    fence()
+    saved = r.read_accum() if (world == 1 and not args.no_roofline_pass) else None
+    r.counters(reset=True)
+    r.kernel_time(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        step(k)
+    fence()
+    dt = time.perf_counter() - t0
+
+    c = r.counters(reset=True)
+    kms, launches = r.kernel_time(reset=True)
+    stats = torch.tensor([dt, float(c["rays"]), float(c["paths"]), kms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, rays, paths, kms_max = float(tmax[0]), float(tsum[1]), float(tsum[2]), float(tmax[3])
+    else:
+        rays, paths, kms_max = float(c["rays"]), float(c["paths"]), kms
+
+    roofline = None
+    if world == 1 and not args.no_roofline_pass:
+        # instrumented replay of exactly the timed frames from the same accumulation state
+        r.write_accum(saved)
+        r.set_counting(True)
+        r.counters(reset=True)
+        for k in range(Wm, Wm + K):
+            r.render(k, seeds[k:k + 1])
+        ci = r.counters(reset=True)
+        r.set_counting(False)
+        assert ci["rays"] == c["rays"], "instrumented replay traced a different number of rays"
+        per_launch = algorithmic_bytes(ci) / launches
+        avg_ms = kms / launches
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as f:
+                t = json.load(f)
+            if t.get("workload") == args.workload:
+                traffic = t.get("hbm_bytes_per_launch")
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 4),
+                    "algorithmic_bytes_per_launch": int(per_launch),
+                    "bytes_per_ray": round(algorithmic_bytes(ci) / ci["rays"], 1),
+                    "boxes_per_ray": round(ci["boxes_tested"] / ci["rays"], 2),
+                    "tris_per_ray": round(ci["tris_tested"] / ci["rays"], 2)}
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (whole node) Sponza 3840x2160 8 bounces; ms/frame at 1 spp",
+            "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "scene_triangles": sc.n_triangles, "bvh_nodes": sc.n_nodes,
+                       "resolution": [W, H], "bounce_limit": bl, "spp_per_step": 1,
+                       "parallelism": "tiles%d" % world if world > 1 else "single",
+                       "rays_per_step": round(rays / K), "mpaths_per_s": round(paths / dt / 1e6, 2),
+                       "trace_kernel_ms_per_step": round(kms_max / K, 4)},
+        }
+        if roofline:
+            out["roofline"] = roofline
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sc, noise, sky, bl, W, H)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

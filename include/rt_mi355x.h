@@ -68,6 +68,7 @@ typedef struct rt_counters {
     uint64_t noise_fetches;  /* texture(u_RgbNoise, ...) calls */
     uint64_t sky_fetches;    /* texture(u_Skybox, ...) calls */
     uint64_t paths;          /* pixel samples finished */
+    uint64_t hits;           /* rays that hit a triangle (full counting only) */
 } rt_counters;
 
 /* Library-level message for failures that happen before a context exists (rt_create). */

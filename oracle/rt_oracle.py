@@ -106,9 +106,9 @@ class Oracle:
         return out
 
     def counters(self, reset=False):
-        c = np.zeros(6, dtype=np.uint64)
+        c = np.zeros(7, dtype=np.uint64)
         self.L.orc_counters(self.h, c.ctypes.data, int(reset))
-        return dict(zip(("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches", "sky_fetches"), map(int, c)))
+        return dict(zip(("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches", "sky_fetches", "hits"), map(int, c)))
 
     def sample_noise(self, s, t):
         out = np.zeros(3, dtype=np.float32)

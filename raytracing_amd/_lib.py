@@ -22,7 +22,7 @@ class rt_camera(ctypes.Structure):
 
 class rt_counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches",
-                                               "sky_fetches", "paths")]
+                                               "sky_fetches", "paths", "hits")]
 
 
 class rth_bvh_stats(ctypes.Structure):

@@ -461,7 +461,7 @@ int rt_get_counters(rt_context* c, rt_counters* out, int reset) {
     HIP_TRY(c, hipMemcpyAsync(t, c->dTotals, sizeof t, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->rays = t[kRays]; out->node_pops = t[kPops]; out->boxes_tested = t[kBoxes]; out->tris_tested = t[kTris];
-    out->noise_fetches = t[kNoise]; out->sky_fetches = t[kSky]; out->paths = t[kPaths] + c->hostPaths;
+    out->noise_fetches = t[kNoise]; out->sky_fetches = t[kSky]; out->paths = t[kPaths] + c->hostPaths; out->hits = t[kHits];
     if (reset) c->hostPaths = 0;
     if (reset) HIP_TRY(c, hipMemsetAsync(c->dTotals, 0, sizeof t, c->stream));
     return RT_OK;

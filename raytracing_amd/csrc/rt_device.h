@@ -87,6 +87,6 @@ struct FrameParams {
     uint32_t frameIndex;
 };
 
-enum CounterSlot { kRays = 0, kPops, kBoxes, kTris, kNoise, kSky, kPaths, kCounterSlots };
+enum CounterSlot { kRays = 0, kPops, kBoxes, kTris, kNoise, kSky, kPaths, kHits, kCounterSlots };
 
 }  // namespace rtd

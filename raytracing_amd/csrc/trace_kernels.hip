@@ -143,7 +143,7 @@ __device__ __forceinline__ bool hit_box(const Ray& r, float mnx, float mny, floa
 
 struct Hit { float t; int index; };
 
-struct Tally { uint32_t rays, pops, boxes, tris, noise, sky, paths; };
+struct Tally { uint32_t rays, pops, boxes, tris, noise, sky, paths, hits; };
 
 // Closest-hit traversal, F:265-326. STACK = LDS entries per lane (>= depth of the deepest interior node).
 template <int STACK, bool COUNT>
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
     uint2* stack = lds_stack + lane;
     const size_t slot = (size_t)localTile * 64 + lane;
 
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     if (valid) {
         const uint32_t BL = sp.bounceLimit;
         const V3 camPos = mk(sp.camPos[0], sp.camPos[1], sp.camPos[2]);
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
                 break;
             }
             const bool hitAnything = hit.index >= 0;
+            if (COUNT && hitAnything) tl.hits++;
             V3 hitPoint = mk(0.0f, 0.0f, 0.0f);
             bool frontFace = false;
             MaterialRec m;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
     }
 
     // per-tile tallies: the owning wave adds its sums (no atomics; one wave owns a tile)
-    uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths};
+    uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths, tl.hits};
     const int nSlots = COUNT ? (int)kCounterSlots : 1;
     for (int s = 0; s < nSlots; ++s) {
         uint32_t v = (s == 0 || COUNT) ? vals[s] : 0u;

@@ -83,7 +83,7 @@ def test_counters_match_oracle(pair):
     o.render(0, SEEDS[:2])
     cg, co = g.counters(reset=True), o.counters(reset=True)
     g.set_counting(False)
-    for k in ("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches", "sky_fetches"):
+    for k in ("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches", "sky_fetches", "hits"):
         assert cg[k] == co[k], k
     assert cg["paths"] == g.W * g.H * 2
     # the uninstrumented kernel counts rays and paths only, and the same number of them
