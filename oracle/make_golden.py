@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ from the REAL reference, in the build container (needs /root/reference
+and Mesa llvmpipe; neither exists on the GPU box, which only reads the committed fixtures).
+
+TEST INFRASTRUCTURE ONLY.
+
+What is recorded (inputs AND the reference's outputs, as data):
+  tracer_*.npz   flat scene arrays + textures + camera + seeds, and the unmodified tracer shader's
+                 output under llvmpipe: BVH heat map (bounce limit 0), |normal| view (1), progressive
+                 radiance for several bounce limits, plus primary-hit (index, t) from the one-line
+                 id patch described in oracle/glsl_ref/reference_renderer.py
+  texture_*.npz  texture() results of llvmpipe for the noise-texture and cube-map samplers
+  bvh_*.npz      triangles in, (nodes, reordered triangles, material ids) out of the reference's
+                 own BvhTree (compiled from its sources into oracle/_ref/libref_host.so)
+  loader_*.npz   object files written by us in the reference's formats (tests/golden/objects/), and
+                 what the reference's ObjectLoader/OFFLoader + BvhTree make of them
+Every file stores a manifest string (Mesa version, flags).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "glsl_ref"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from glref import GLRef  # noqa: E402
+from reference_renderer import ReferenceRenderer  # noqa: E402
+import raytracing_amd as ra  # noqa: E402
+from raytracing_amd import scenes  # noqa: E402
+from util import DEFAULT_CAMERA, FOV, VPW  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+f32 = np.float32
+
+
+def manifest(gl):
+    return "%s; GALLIVM_PERF=%s; LP_NUM_THREADS=%s; generator oracle/make_golden.py" % (
+        gl.renderer(), os.environ.get("GALLIVM_PERF", "(unset: default 8-bit AoS sampling)"), os.environ.get("LP_NUM_THREADS", "(unset)"))
+
+
+def scene_from(objs, tmp):
+    paths = scenes.write_objects(objs, tmp)
+    return ra.load_scene(paths, build_threads=4)
+
+
+def tracer_fixture(gl, name, sc, W, H, camera, noise, sky, radiance_cases, n_seeds=16):
+    seeds = scenes.frame_seeds(n_seeds)
+    out = dict(tri12=sc.tri12, matidx=sc.matidx, node8=sc.node8, materials=sc.materials, noise=noise, sky=sky,
+               cam_position=np.asarray(camera["position"], f32), cam_facing=np.asarray(camera["facing"], f32),
+               cam_fov=f32(camera["fov"]), cam_vpw=f32(camera["viewport_width"]), width=W, height=H, seeds=seeds)
+
+    def setup(r):
+        r.set_scene(sc.tri12, sc.matidx, sc.node8)
+        r.set_materials(sc.materials)
+        r.set_camera(**camera)
+        r.set_noise(noise)
+        r.set_skybox(sky)
+
+    ids = ReferenceRenderer(W, H, ids=True, gl=gl)
+    setup(ids)
+    ids.set_bounce_limit(1)
+    ids.render(0, seeds[:1])
+    a = ids.read_accum()
+    out["ids_index"] = a[..., 0].astype(np.int32)
+    out["ids_t"] = a[..., 1].copy()
+    out["ids_hit"] = a[..., 2].astype(np.uint8)
+
+    ref = ReferenceRenderer(W, H, ids=False, gl=gl)
+    setup(ref)
+    for bl, key in ((0, "heat"), (1, "normals")):
+        ref.clear()
+        ref.set_bounce_limit(bl)
+        ref.render(0, seeds[:1])
+        out[key] = ref.read_accum()[..., :3].copy()
+    for bl, frames in radiance_cases:
+        ref.clear()
+        ref.set_bounce_limit(bl)
+        ref.render(0, seeds[:frames])
+        out["radiance_b%d_f%d" % (bl, frames)] = ref.read_accum()[..., :3].copy()
+    out["manifest"] = manifest(gl)
+    np.savez_compressed(os.path.join(GOLD, "tracer_%s.npz" % name), **out)
+    print("tracer_%s: %d tris, %dx%d, hit pixels %d" % (name, sc.n_triangles, W, H, int((out["ids_index"] >= 0).sum())))
+
+
+def texture_fixture(gl):
+    sys.path.insert(0, os.path.join(HERE, "glsl_ref"))
+    from probe_tex import prog
+    rng = np.random.default_rng(11)
+    out = {"manifest": manifest(gl)}
+    t = gl.tex_f32(0, 4, 4)
+    fb = gl.fbo(t)
+    p2 = prog(gl, "#version 430 core\nout vec4 color;\nuniform sampler2D T;\nuniform vec2 P;\nvoid main(){ color = vec4(texture(T, P).rgb, 1.0); }\n")
+    for tag, (w, h) in (("a", (600, 400)), ("b", (37, 23))):
+        tex = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        gl.tex_rgb8(2, tex)
+        gl.u1i(p2, "T", 2)
+        coords = rng.uniform(-4, 4, size=(400, 2)).astype(f32)
+        coords[:20] = rng.integers(-3, 4, size=(20, 2)).astype(f32) + rng.choice([0.0, 0.5 / w, 1.0 / w, 0.5], size=(20, 2)).astype(f32)
+        res = np.zeros((len(coords), 3), f32)
+        for i, c in enumerate(coords):
+            gl.u2f(p2, "P", float(c[0]), float(c[1]))
+            gl.draw(p2, fb, 4, 4)
+            res[i] = gl.read_f32(0, t, 4, 4)[0, 0, :3]
+        out["noise_%s_tex" % tag], out["noise_%s_coords" % tag], out["noise_%s_result" % tag] = tex, coords, res
+    pc = prog(gl, "#version 430 core\nout vec4 color;\nuniform samplerCube T;\nuniform vec3 D;\nvoid main(){ color = vec4(texture(T, D).rgb, 1.0); }\n")
+    for tag, size in (("a", 16), ("b", 61)):
+        faces = rng.integers(0, 256, size=(6, size, size, 4), dtype=np.uint8)
+        gl.cubemap(3, faces)
+        gl.u1i(pc, "T", 3)
+        dirs = rng.standard_normal((500, 3)).astype(f32)
+        dirs[:30, rng.integers(0, 3, 30)] *= f32(0.001)          # near-axis directions, face edges
+        res = np.zeros((len(dirs), 3), f32)
+        for i, d in enumerate(dirs):
+            gl.u3f(pc, "D", float(d[0]), float(d[1]), float(d[2]))
+            gl.draw(pc, fb, 4, 4)
+            res[i] = gl.read_f32(0, t, 4, 4)[0, 0, :3]
+        out["sky_%s_faces" % tag], out["sky_%s_dirs" % tag], out["sky_%s_result" % tag] = faces, dirs, res
+    np.savez_compressed(os.path.join(GOLD, "texture_filter.npz"), **out)
+    print("texture_filter: done")
+
+
+class RefHost:
+    def __init__(self):
+        L = ctypes.CDLL(os.path.join(HERE, "_ref", "libref_host.so"))
+        for f in ("ref_scene_build", "ref_scene_load", "ref_scene_tri12", "ref_scene_matidx", "ref_scene_node8", "ref_scene_mats11"):
+            getattr(L, f).restype = ctypes.c_void_p
+        L.ref_scene_log.restype = ctypes.c_char_p
+        for f in ("ref_scene_triangle_count", "ref_scene_node_count", "ref_scene_material_count", "ref_scene_log", "ref_scene_free",
+                  "ref_scene_tri12", "ref_scene_matidx", "ref_scene_node8", "ref_scene_mats11"):
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        self.L = L
+
+    def _collect(self, h):
+        L = self.L
+        n, m, k = L.ref_scene_triangle_count(h), L.ref_scene_node_count(h), L.ref_scene_material_count(h)
+
+        def arr(ptr, cnt, ct):
+            return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(cnt,)).copy() if cnt else np.zeros(0, ct)
+        r = dict(tri12=arr(L.ref_scene_tri12(h), n * 12, ctypes.c_float), matidx=arr(L.ref_scene_matidx(h), n, ctypes.c_int32),
+                 node8=arr(L.ref_scene_node8(h), m * 8, ctypes.c_float), mats11=arr(L.ref_scene_mats11(h), k * 11, ctypes.c_float),
+                 log=L.ref_scene_log(h).decode())
+        L.ref_scene_free(h)
+        return r
+
+    def build(self, tri9, mat):
+        tri9 = np.ascontiguousarray(tri9, f32).reshape(-1, 9)
+        mat = np.ascontiguousarray(mat, np.int32)
+        h = ctypes.c_void_p(self.L.ref_scene_build(tri9.ctypes.data_as(ctypes.c_void_p), mat.ctypes.data_as(ctypes.c_void_p), len(mat)))
+        return self._collect(h)
+
+    def load(self, paths):
+        arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+        first = ctypes.c_int32(-1)
+        h = ctypes.c_void_p(self.L.ref_scene_load(arr, len(paths), ctypes.byref(first)))
+        r = self._collect(h)
+        r["first_slot"] = first.value
+        return r
+
+
+def bvh_fixtures(ref):
+    rng = np.random.default_rng(5)
+    cases = {}
+    n = 1500
+    c = rng.uniform(-5, 5, size=(n, 1, 3))
+    cases["random1500"] = (c + rng.normal(0, 0.3, size=(n, 3, 3))).astype(f32).reshape(n, 9)
+    cases["duplicates50"] = np.tile(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], f32), (50, 1))
+    g = 24
+    xs, ys = np.meshgrid(np.arange(g), np.arange(g))
+    p = np.stack([xs, ys, np.sin(xs * 0.3) * np.cos(ys * 0.2)], -1).astype(f32)
+    a, b, cc, d = p[:-1, :-1], p[1:, :-1], p[:-1, 1:], p[1:, 1:]
+    cases["grid24"] = np.concatenate([np.stack([a, b, cc], 2).reshape(-1, 9), np.stack([b, d, cc], 2).reshape(-1, 9)])
+    cases["flat_coplanar"] = np.concatenate([cases["grid24"][:200] * f32([1, 1, 0] * 3)])   # zero-extent axis
+    for k in (1, 2, 3, 4, 5, 7, 9):
+        cases["tiny%d" % k] = cases["random1500"][:k]
+    out = {}
+    for name, tri9 in cases.items():
+        mat = (np.arange(len(tri9)) % 5).astype(np.int32)
+        r = ref.build(tri9, mat)
+        out[name + "_in_tri9"], out[name + "_in_mat"] = tri9, mat
+        out[name + "_tri12"], out[name + "_matidx"], out[name + "_node8"] = r["tri12"], r["matidx"], r["node8"]
+        out[name + "_log"] = r["log"]
+    out["manifest"] = "reference BvhTree.cpp/ObjectLoader.h compiled with g++ -O3 (oracle/Makefile); generator oracle/make_golden.py"
+    np.savez_compressed(os.path.join(GOLD, "bvh_reference.npz"), **out)
+    print("bvh_reference: %d cases" % len(cases))
+
+
+LOADER_FILES = {
+    "plain.txt": "lambertian 0.2 0.4 0.6\n2\n0 0 0 1 0 0 0 1 0\n0 0 1  1 0 1  0 1 1\n",
+    "placed.txt": "position 1 2 3\nscale 0.5\nformat xzy\nmetallic 0.8 0.8 0.9 0.1 1.0\n3\n0 0 0 1 0 0 0 1 0\n1 1 1 2 1 1 1 2 1\n-1 -1 -1 -2 -1 -1 -1 -2 -1\n",
+    "default.txt": "scale 2\ndefault-material\n1\n0 0 0 0 1 0 0 0 1\n",
+    "glass.off": "format xyz position 0 0 -2 transparent 1 1 1 0.9 1.5\nOFF\n4 4 0\n0 0 0\n1 0 0\n0 1 0\n0 0 1\n3 0 1 2\n3 0 1 3\n3 0 2 3\n3 1 2 3\n",
+    "mirror.OFF": "specular 0.9 0.9 0.95 0.05\nOFF\n3 1 0\n0 0 5\n1 0 5\n0 1 5\n3 2 1 0\n",
+    "lamp.txt": "lightsource 1 0.9 0.8 5\n1\n0 0 3 1 0 3 0 1 3\n",
+    "cloud.off": "scale 3 lambertian 0.5 0.5 0.5\nOFF\n3 0 0\n0.1 0.2 0.3\n1 1 1\n-2 0.5 4\n",
+    "badformat.txt": "format zyx\nlambertian 1 0 0\n1\n0 0 0 1 0 0 0 1 0\n",
+    "nomaterial.txt": "position 1 2 3\n",
+    "unknownmat.txt": "plastic 1 1 1\n1\n0 0 0 1 0 0 0 1 0\n",
+    "truncated.txt": "lambertian 0.3 0.3 0.3\n3\n0 0 0 1 0 0 0 1 0\n1 1 1\n",
+    "empty_count.txt": "lambertian 0.3 0.3 0.3\n",
+}
+
+
+def loader_fixtures(ref):
+    d = os.path.join(GOLD, "objects")
+    os.makedirs(d, exist_ok=True)
+    for name, text in LOADER_FILES.items():
+        with open(os.path.join(d, name), "w") as f:
+            f.write(text)
+    out = {}
+    groups = {
+        "all_good": ["plain.txt", "placed.txt", "default.txt", "glass.off", "mirror.OFF", "lamp.txt", "cloud.off"],
+        "with_failures": ["plain.txt", "missing_file.txt", "nomaterial.txt", "unknownmat.txt", "truncated.txt", "badformat.txt", "lamp.txt", "empty_count.txt"],
+    }
+    for g, names in groups.items():
+        r = ref.load([os.path.join(d, n) for n in names])
+        base = r["first_slot"] if r["first_slot"] >= 0 else 0
+        out[g + "_files"] = np.array(names)
+        out[g + "_tri12"], out[g + "_node8"] = r["tri12"], r["node8"]
+        # the reference numbers materials with a process-wide counter; rebase to this scene
+        out[g + "_matidx_rebased"] = r["matidx"] - base
+        out[g + "_mats11"] = r["mats11"]
+        out[g + "_log"] = r["log"]
+        print("loader %s: %d tris, %d materials, first slot %d" % (g, len(r["matidx"]), len(r["mats11"]) // 11, r["first_slot"]))
+    out["manifest"] = "reference ObjectLoader.h/BvhTree.cpp compiled with g++ -O3; object files written by oracle/make_golden.py"
+    np.savez_compressed(os.path.join(GOLD, "loader_reference.npz"), **out)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    gl = GLRef()
+    noise = scenes.noise_texture(64, 48, seed=7)
+    sky = scenes.sky_cubemap(32, seed=3)
+    cam2 = dict(position=(1.5, -2.0, 0.7), facing=tuple(float(x) for x in (np.array([0.8, 0.55, -0.2], f32) / np.linalg.norm(np.array([0.8, 0.55, -0.2], f32)))),
+                fov=float(FOV), viewport_width=VPW)
+    zoom = dict(DEFAULT_CAMERA)
+    zoom["viewport_width"] = float(f32(2.0 * np.tan(float(f32(90 * 0.01745329251994329576923690768489)) / 2.0)))   # the C key: 90 degrees
+    tracer_fixture(gl, "lightbox", scene_from(scenes.lightbox(), tmp + "/a"), 96, 54, DEFAULT_CAMERA, noise, sky,
+                   [(2, 4), (4, 16), (8, 4), (32, 2)])
+    tracer_fixture(gl, "lightbox_cam2", scene_from(scenes.lightbox(), tmp + "/a2"), 72, 40, cam2, noise, sky, [(4, 6)])
+    tracer_fixture(gl, "sponza_small", scene_from(scenes.sponza_like(target_tris=6000), tmp + "/b"), 96, 56, DEFAULT_CAMERA, noise, sky,
+                   [(8, 6), (4, 4)])
+    tracer_fixture(gl, "dragon_small", scene_from(scenes.dragon_like(target_tris=4000), tmp + "/c"), 64, 40, zoom, noise, sky,
+                   [(16, 8)])
+    tracer_fixture(gl, "teapot_small", scene_from(scenes.teapot_like(target_tris=4000), tmp + "/d"), 70, 38, DEFAULT_CAMERA, noise, sky,
+                   [(8, 8)])
+    texture_fixture(gl)
+    ref = RefHost()
+    bvh_fixtures(ref)
+    loader_fixtures(ref)
+
+
+if __name__ == "__main__":
+    main()
