@@ -14,8 +14,11 @@
 #include "rt_mi355x.h"
 
 namespace rtd {
-void LaunchTrace(int stackEntries, bool count, bool ids, hipStream_t st, uint32_t nBlocks, const SceneParams& sp, const FrameParams* frames,
-                 uint32_t nFrames, void* accum, uint32_t* tally, int32_t* idsOut);
+void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
+                 void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
+                 uint32_t tilesPerGroup);
+uint32_t SpillEntriesPerWave();
+uint32_t ResidentWaves();
 void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots);
 void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t width, uint32_t height, uint32_t tilesX, uint32_t world,
                   uint32_t shardTiles, bool toTiled);
@@ -39,11 +42,13 @@ struct rt_context {
     void* dAccum = nullptr;          // tile-major shard, shardTiles*64 float4
     void* dLinear = nullptr;         // row-major staging image, width*height float4
     FrameParams* dFrames = nullptr; uint32_t framesCap = 0;
-    uint32_t* dTally = nullptr;      // [kCounterSlots][shardTiles]
+    uint32_t* dTally = nullptr;      // [kCounterSlots][maxWaves]
+    void* dSpill = nullptr;          // stack spill area, maxWaves * SpillEntriesPerWave() * 8 bytes
+    uint32_t* dQueue = nullptr;      // 64 words; the first 8 are the per-band group counters
+    uint32_t maxWaves = 0;           // persistent grid size limit (resident waves of the device)
     unsigned long long* dTotals = nullptr;   // [kCounterSlots]
     int32_t* dIds = nullptr;
     void* postScratch = nullptr;
-    int stackEntries = 16;
     bool haveNoise = false, haveSky = false, haveScene = false;
     bool countAll = false;
     uint64_t hostPaths = 0;          // pixel samples rendered while full counting was off
@@ -75,15 +80,11 @@ uint32_t ShardTiles(const rt_context* c) {
 
 int AllocShard(rt_context* c) {
     if (c->dAccum) { (void)hipFree(c->dAccum); c->dAccum = nullptr; }
-    if (c->dTally) { (void)hipFree(c->dTally); c->dTally = nullptr; }
     if (c->dIds) { (void)hipFree(c->dIds); c->dIds = nullptr; }
     c->sp.shardTiles = ShardTiles(c);
     size_t bytes = (size_t)c->sp.shardTiles * 64 * sizeof(float) * 4;
     HIP_TRY(c, hipMalloc(&c->dAccum, bytes));
     HIP_TRY(c, hipMemsetAsync(c->dAccum, 0, bytes, c->stream));
-    size_t tb = (size_t)kCounterSlots * c->sp.shardTiles * sizeof(uint32_t);
-    HIP_TRY(c, hipMalloc((void**)&c->dTally, tb));
-    HIP_TRY(c, hipMemsetAsync(c->dTally, 0, tb, c->stream));
     return RT_OK;
 }
 
@@ -139,6 +140,13 @@ int rt_create(int device, uint32_t width, uint32_t height, rt_context** out) {
         if (me == hipSuccess) me = hipMalloc((void**)&c->dTotals, sizeof(unsigned long long) * kCounterSlots);
         if (me == hipSuccess) me = hipMemsetAsync(c->dTotals, 0, sizeof(unsigned long long) * kCounterSlots, c->stream);
         if (me == hipSuccess) me = hipMalloc(&c->dLinear, (size_t)width * height * 16);
+        c->maxWaves = ResidentWaves();
+        if (me == hipSuccess && c->maxWaves == 0) me = hipErrorUnknown;
+        const size_t tb = (size_t)kCounterSlots * c->maxWaves * sizeof(uint32_t);
+        if (me == hipSuccess) me = hipMalloc((void**)&c->dTally, tb);
+        if (me == hipSuccess) me = hipMemsetAsync(c->dTally, 0, tb, c->stream);
+        if (me == hipSuccess) me = hipMalloc(&c->dSpill, (size_t)c->maxWaves * SpillEntriesPerWave() * 8);
+        if (me == hipSuccess) me = hipMalloc((void**)&c->dQueue, 256);
         if (me != hipSuccess) rc = Fail(c, RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(me));
     }
     if (rc != RT_OK) { g_globalError = c->error; rt_destroy(c); return rc; }
@@ -154,7 +162,7 @@ void rt_destroy(rt_context* c) {
     for (auto& pr : c->pendingEvents) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : c->freeEvents) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     FreePostprocess(&c->postScratch);
-    void* ptrs[] = {c->dNodes, c->dTris, c->dNoise, c->dSky, c->dMaterials, c->dAccum, c->dLinear, c->dFrames, c->dTally, c->dTotals, c->dIds};
+    void* ptrs[] = {c->dNodes, c->dTris, c->dNoise, c->dSky, c->dMaterials, c->dAccum, c->dLinear, c->dFrames, c->dTally, c->dTotals, c->dIds, c->dSpill, c->dQueue};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -246,7 +254,6 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
         sp.rootRef = in.count > 0 ? MakeLeafRef((uint32_t)in.ref, (uint32_t)in.count) : 0u;
         for (int k = 0; k < 3; ++k) { sp.rootMax[k] = node8[k]; sp.rootMin[k] = node8[3 + k]; }
     }
-    c->stackEntries = maxInteriorDepth <= 16 ? 16 : (maxInteriorDepth <= 32 ? 32 : 64);
     c->haveScene = true;
     return RT_OK;
 }
@@ -340,6 +347,17 @@ int rt_accum_read(rt_context* c, float* rgba) {
     return RT_OK;
 }
 
+// Queues one launch of the persistent tracer over this context's shard.
+static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
+    const uint32_t tilesPerGroup = 2;
+    const uint32_t nGroups = (c->sp.shardTiles + tilesPerGroup - 1) / tilesPerGroup;
+    const uint32_t nWaves = std::max<uint32_t>(1u, std::min<uint32_t>(nGroups, c->maxWaves));
+    HIP_TRY(c, hipMemsetAsync(c->dQueue, 0, 256, c->stream));
+    LaunchTrace(count, ids, c->stream, nWaves, c->sp, c->dFrames, nFrames, c->dAccum, c->dTally, c->maxWaves, c->dIds, c->dSpill, c->dQueue, nGroups, tilesPerGroup);
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
+}
+
 static int CheckRenderable(rt_context* c, const char* who) {
     if (!c->haveNoise) return Fail(c, RT_ERR_STATE, "%s: no noise texture (rt_set_noise)", who);
     if (!c->haveSky) return Fail(c, RT_ERR_STATE, "%s: no skybox (rt_set_skybox)", who);
@@ -388,8 +406,8 @@ int rt_render(rt_context* c, uint32_t firstFrameIndex, uint32_t nFrames, const f
     if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
     else { HIP_TRY(c, hipEventCreate(&ev.first)); HIP_TRY(c, hipEventCreate(&ev.second)); }
     HIP_TRY(c, hipEventRecord(ev.first, c->stream));
-    LaunchTrace(c->stackEntries, c->countAll, false, c->stream, c->sp.shardTiles, c->sp, c->dFrames, nFrames, c->dAccum, c->dTally, nullptr);
-    HIP_TRY(c, hipGetLastError());
+    rc = LaunchShard(c, c->countAll, false, nFrames);
+    if (rc != RT_OK) return rc;
     HIP_TRY(c, hipEventRecord(ev.second, c->stream));
     c->pendingEvents.push_back(ev);
     if (!c->countAll) {
@@ -425,8 +443,8 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) {
     const size_t n = (size_t)c->sp.shardTiles * 64;
     if (!c->dIds) HIP_TRY(c, hipMalloc((void**)&c->dIds, n * 3 * sizeof(int32_t)));
     HIP_TRY(c, hipMemsetAsync(c->dIds, 0xff, n * 3 * sizeof(int32_t), c->stream));
-    LaunchTrace(c->stackEntries, true, true, c->stream, c->sp.shardTiles, c->sp, c->dFrames, 1, c->dAccum, c->dTally, c->dIds);
-    HIP_TRY(c, hipGetLastError());
+    rc = LaunchShard(c, true, true, 1);
+    if (rc != RT_OK) return rc;
     std::vector<int32_t> tiled(n * 3);
     HIP_TRY(c, hipMemcpyAsync(tiled.data(), c->dIds, n * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -436,7 +454,7 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) {
             std::memcpy(out3 + ((size_t)y * c->width + x) * 3, tiled.data() + slot * 3, 3 * sizeof(int32_t));
         }
     // the id pass also ran the tallies; drop them so that counters describe rt_render only
-    HIP_TRY(c, hipMemsetAsync(c->dTally, 0, (size_t)kCounterSlots * c->sp.shardTiles * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dTally, 0, (size_t)kCounterSlots * c->maxWaves * sizeof(uint32_t), c->stream));
     return RT_OK;
 }
 
@@ -455,7 +473,7 @@ int rt_postprocess(rt_context* c, int bloom_on, float* rgba_out, uint8_t* rgb8_o
 int rt_get_counters(rt_context* c, rt_counters* out, int reset) {
     if (!c || !out) return c ? Fail(c, RT_ERR_INVALID, "rt_get_counters: NULL out") : RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    LaunchReduceTally(c->stream, c->dTally, c->sp.shardTiles, c->dTotals, kCounterSlots);
+    LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);
     HIP_TRY(c, hipGetLastError());
     unsigned long long t[kCounterSlots];
     HIP_TRY(c, hipMemcpyAsync(t, c->dTotals, sizeof t, hipMemcpyDeviceToHost, c->stream));

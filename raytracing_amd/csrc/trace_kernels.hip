@@ -1,23 +1,30 @@
-// Path-tracing kernels for gfx950 (MI355X): one wave64 per 8x8 pixel tile, one lane per pixel.
+// Path-tracing kernels for gfx950 (MI355X).
 //
-// What is computed is the reference's tracer pass (src/shaders/Fragment.glsl of the reference,
+// WHAT is computed is the reference's tracer pass (src/shaders/Fragment.glsl of the reference,
 // cited below as F:<line>), with every floating-point operation in the same order and rounding
 // as that shader evaluates it under Mesa llvmpipe: reversed three-term dot products, normalize as
 // multiply by 1/sqrt, mix as a + t*(b-a), IEEE division and square root, denormals flushed, and
 // llvmpipe's 8-bit fixed-point bilinear texture filter. This file must be compiled with
 // -ffp-contract=off -fgpu-flush-denormals-to-zero (see Makefile); results are then bit-identical
-// to the CPU parity oracle.
+// to the CPU parity oracle, and per-pixel results do not depend on how pixels are scheduled.
 //
-// How it is computed is specific to this hardware:
+// HOW it is computed is specific to this hardware:
 //   * BVH: 64-byte records hold both children of an interior node, leaves are encoded in the
 //     child reference, so a visit is one aligned 64 B fetch instead of three 32 B fetches and the
 //     second AABB test the shader performs when it pops a node is replaced by the entry distance
 //     remembered from when it was pushed (same value, same comparison).
-//   * The near child is descended into directly; only the far child goes to the stack, which lives
-//     in LDS as [entry][lane] (conflict-free: each lane owns a column) with 8-byte entries.
-//   * Lanes are persistent over frames: a lane that finishes its path starts the next frame's
-//     path for its pixel at once while its neighbours are still bouncing, and the running mean
-//     stays in registers; the accumulation image is read and written once per launch.
+//   * The near child is descended into directly; only the far child goes to a stack whose first
+//     kLdsStack entries live in LDS as [entry][lane] (conflict-free: each lane owns a column,
+//     8-byte entries) and whose rare deeper entries spill to a per-wave HBM area.
+//   * Persistent waves: the grid is sized to the machine, each wave pulls groups of 8x8-pixel
+//     tiles from per-XCD queues (one returning atomic per group; neighbouring tiles stay on one
+//     XCD's L2), and a lane that finishes a pixel takes the next pixel of the wave's pool at once.
+//   * Wave-level scheduling by ballot: every lane is in one of four states (new path, interior
+//     node, leaf, shade); each round the wave runs the body of the most populated state, so the
+//     long interior-node loop, the triangle tests and the material code each run with many lanes
+//     instead of every round executing all three for a few lanes each.
+//   * Lanes are persistent over frames too: the running mean of a pixel stays in registers for all
+//     frames of a launch; the accumulation image is read and written once per launch.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -141,268 +148,359 @@ __device__ __forceinline__ bool hit_box(const Ray& r, float mnx, float mny, floa
     return hi >= fmaxf(lo, 0.0f);
 }
 
-struct Hit { float t; int index; };
 
 struct Tally { uint32_t rays, pops, boxes, tris, noise, sky, paths, hits; };
 
-// Closest-hit traversal, F:265-326. STACK = LDS entries per lane (>= depth of the deepest interior node).
-template <int STACK, bool COUNT>
-__device__ __forceinline__ void traverse(const SceneParams& sp, const Ray& ray, uint2* __restrict__ stack /* this lane's column */,
-                                         Hit& best, int& iterations, Tally& tl) {
-    best.t = INFINITY; best.index = -1;
-    int iters = 0;
-    int top = 0;                       // number of deferred entries of this lane
-    uint32_t cur = kNoRef;
-    if (sp.rootRef != kNoRef) {
-        iters = 1;
-        float tr;
-        if (COUNT) tl.boxes++;
-        if (hit_box(ray, sp.rootMin[0], sp.rootMin[1], sp.rootMin[2], sp.rootMax[0], sp.rootMax[1], sp.rootMax[2], tr) && !(tr >= best.t))
-            cur = sp.rootRef;
-    }
-    for (;;) {
-        if (cur == kNoRef) {
-            // pop: F:277-283 with the entry distance remembered from push time
-            if (top == 0) break;
-            --top;
-            uint2 e = stack[top * 64];
-            iters++;
-            if (__uint_as_float(e.y) >= best.t) continue;
-            cur = e.x;
-        }
-        if (cur & kLeafBit) {
-            // leaf: F:285-295, triangles in order, strictly closer wins
-            uint32_t first = cur & 0x07ffffffu, count = ((cur >> 27) & 15u) + 1u;
-            for (uint32_t i = first; i < first + count; ++i) {
-                const float4* T = reinterpret_cast<const float4*>(sp.tris + i);
-                float4 a = T[0], b = T[1], c = T[2];
-                if (COUNT) tl.tris++;
-                V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
-                V3 h = cross3(ray.d, e2);                       // F:207-240
-                float det = dot3(e1, h);
-                if (fabsf(det) < 1e-8f) continue;
-                float invDet = 1.0f / det;
-                V3 s = ray.o - v0;
-                float u = invDet * dot3(s, h);
-                if (u < 0.0f || u > 1.0f) continue;
-                V3 q = cross3(s, e1);
-                float v = invDet * dot3(ray.d, q);
-                if (v < 0.0f || u + v > 1.0f) continue;
-                float t = invDet * dot3(e2, q);
-                if (t < 0.0001f) continue;
-                if (best.t > t) { best.t = t; best.index = (int)i; }
-            }
-            cur = kNoRef;
-        } else {
-            // interior: both children from one 64-byte record, F:296-311
-            const float4* N = reinterpret_cast<const float4*>(sp.nodes + cur);
-            float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
-            if (COUNT) tl.boxes += 2;
-            float tL, tR;
-            bool hL = hit_box(ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tL);
-            bool hR = hit_box(ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tR);
-            uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
-            bool okL = hL && tL < best.t, okR = hR && tR < best.t;
-            // the child pushed last is popped next; `tL < tR` decides which one that is
-            bool leftFirst = tL < tR;
-            uint32_t nearRef = leftFirst ? refL : refR, farRef = leftFirst ? refR : refL;
-            float nearT = leftFirst ? tL : tR, farT = leftFirst ? tR : tL;
-            bool okNear = leftFirst ? okL : okR, okFar = leftFirst ? okR : okL;
-            (void)nearT;
-            if (okNear) {
-                if (okFar) { stack[top * 64] = make_uint2(farRef, __float_as_uint(farT)); ++top; }
-                iters++;               // the immediate pop of the near child (its test passes: best.t is unchanged)
-                cur = nearRef;
-            } else if (okFar) {
-                iters++;
-                cur = farRef;
-            } else {
-                cur = kNoRef;
-            }
-        }
-    }
-    iterations = iters;
-    if (COUNT) { tl.pops += (uint32_t)iters; }
-    tl.rays++;
-}
+enum LaneState : int { kIdle = 0, kNewPath = 1, kInterior = 2, kLeaf = 3, kShade = 4 };
 
-// Per-lane path state carried across traversals.
-struct Path {
+constexpr int kLdsStack = 16;          // stack entries per lane kept in LDS (8 KiB per wave)
+
+// Everything a lane carries between scheduler rounds.
+struct Lane {
+    int state;
+    uint32_t slot;          // tile-major pixel slot of this shard (tile * 64 + lane-in-tile)
+    uint32_t k;             // frame counter within the launch
+    V3 previous;            // running mean of the pixel (F:455,487)
+    V3 throughput;          // rayColour (F:382)
     Ray ray;
-    V3 throughput;      // rayColour
-    int bounce;         // i
+    int bounce;             // i of the bounce loop (F:384)
+    uint32_t segments;      // traversals of the current path
+    // traversal (F:265-326)
+    uint32_t cur;           // node / leaf reference being visited
+    int top;                // deferred stack entries
+    float bestT; int bestIdx;
+    int iters;              // iterationsCount
 };
 
-template <int STACK, bool COUNT, bool IDS>
-__global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
-                                                   float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][shardTiles] */,
-                                                   int32_t* __restrict__ ids /* IDS only: [tile*64+lane][3] */, uint32_t nBlocks) {
-    __shared__ uint2 lds_stack[STACK * 64];
-    const uint32_t lane = threadIdx.x;
-    // XCD-aware tile order: consecutive blocks go round-robin over the 8 XCDs, so give each XCD
-    // a contiguous band of tiles (neighbouring tiles walk the same BVH subtrees -> shared L2).
-    uint32_t b = blockIdx.x;
-    {
-        const uint32_t q = nBlocks / 8u, r = nBlocks % 8u, xcd = b % 8u;
-        b = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + b / 8u;
+struct StackRef {
+    uint2* lds;             // this lane's LDS column, stride 64
+    uint2* spill;           // this lane's HBM column, stride 64 (entries kLdsStack .. kMaxStack-1)
+};
+
+__device__ __forceinline__ void push(const StackRef& st, int& top, uint32_t ref, float t) {
+    uint2 e = make_uint2(ref, __float_as_uint(t));
+    if (top < kLdsStack) st.lds[top * 64] = e; else st.spill[(top - kLdsStack) * 64] = e;
+    ++top;
+}
+
+// Pops deferred nodes until one is still worth visiting (F:277-283 with the entry distance kept
+// from push time). Sets the lane's next state.
+template <bool COUNT>
+__device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
+    for (;;) {
+        if (L.top == 0) { L.cur = kNoRef; L.state = kShade; return; }
+        --L.top;
+        uint2 e = (L.top < kLdsStack) ? st.lds[L.top * 64] : st.spill[(L.top - kLdsStack) * 64];
+        L.iters++;
+        if (__uint_as_float(e.y) >= L.bestT) continue;
+        L.cur = e.x;
+        L.state = (e.x & kLeafBit) ? kLeaf : kInterior;
+        return;
     }
-    const uint32_t localTile = b;
-    const uint32_t tile = localTile * sp.shardWorld + sp.shardRank;
+}
+
+// Starts the traversal of L.ray: the root's own box test (the first pop of F:276-283).
+template <bool COUNT>
+__device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, Tally& tl) {
+    L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0; L.top = 0; L.cur = kNoRef;
+    L.state = kShade;
+    tl.rays++;
+    if (sp.rootRef != kNoRef) {
+        L.iters = 1;
+        float tr;
+        if (COUNT) tl.boxes++;
+        if (hit_box(L.ray, sp.rootMin[0], sp.rootMin[1], sp.rootMin[2], sp.rootMax[0], sp.rootMax[1], sp.rootMax[2], tr) && !(tr >= L.bestT)) {
+            L.cur = sp.rootRef;
+            L.state = (sp.rootRef & kLeafBit) ? kLeaf : kInterior;
+        }
+    }
+}
+
+// One interior node: both children from one 64-byte record, F:296-311.
+template <bool COUNT>
+__device__ __forceinline__ void interior_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
+    const float4* N = reinterpret_cast<const float4*>(sp.nodes + L.cur);
+    float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+    if (COUNT) tl.boxes += 2;
+    float tL, tR;
+    bool hL = hit_box(L.ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tL);
+    bool hR = hit_box(L.ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tR);
+    uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
+    bool okL = hL && tL < L.bestT, okR = hR && tR < L.bestT;
+    // the child pushed last is popped next; `tL < tR` decides which one that is
+    bool leftFirst = tL < tR;
+    uint32_t nearRef = leftFirst ? refL : refR, farRef = leftFirst ? refR : refL;
+    float farT = leftFirst ? tR : tL;
+    bool okNear = leftFirst ? okL : okR, okFar = leftFirst ? okR : okL;
+    if (okNear | okFar) {
+        if (okNear & okFar) push(st, L.top, farRef, farT);
+        L.iters++;               // the immediate pop of the chosen child (its test passes: bestT is unchanged)
+        L.cur = okNear ? nearRef : farRef;
+        L.state = (L.cur & kLeafBit) ? kLeaf : kInterior;
+    } else {
+        pop_next<COUNT>(st, L);
+    }
+}
+
+// One leaf: F:285-295 with hitTriangle F:207-240; triangles in order, strictly closer wins.
+template <bool COUNT>
+__device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
+    const uint32_t first = L.cur & 0x07ffffffu, count = ((L.cur >> 27) & 15u) + 1u;
+    for (uint32_t i = first; i < first + count; ++i) {
+        const float4* T = reinterpret_cast<const float4*>(sp.tris + i);
+        float4 a = T[0], b = T[1], c = T[2];
+        if (COUNT) tl.tris++;
+        V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
+        V3 h = cross3(L.ray.d, e2);
+        float det = dot3(e1, h);
+        float invDet = 1.0f / det;
+        V3 s = L.ray.o - v0;
+        float u = invDet * dot3(s, h);
+        V3 q = cross3(s, e1);
+        float v = invDet * dot3(L.ray.d, q);
+        float t = invDet * dot3(e2, q);
+        // the shader's four early returns, with its comparison operators (NaNs fall through them)
+        bool reject = (fabsf(det) < 1e-8f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < 0.0001f);
+        if (!reject && L.bestT > t) { L.bestT = t; L.bestIdx = (int)i; }
+    }
+    pop_next<COUNT>(st, L);
+}
+
+template <bool COUNT, bool IDS>
+__global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
+                                                   float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
+                                                   int32_t* __restrict__ ids /* IDS only: [slot][3] */,
+                                                   uint2* __restrict__ spillArea /* [gridDim.x][kMaxStack-kLdsStack][64] */,
+                                                   uint32_t* __restrict__ queueHeads /* [8] next group per band, zeroed before the launch */,
+                                                   uint32_t nGroups, uint32_t tilesPerGroup, uint32_t tallyStride) {
+    __shared__ uint2 lds_stack[kLdsStack * 64];
+    const uint32_t lane = threadIdx.x;
+    StackRef st;
+    st.lds = lds_stack + lane;
+    st.spill = spillArea + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64 + lane;
+
+    const uint32_t BL = sp.bounceLimit;
+    const V3 camPos = mk(sp.camPos[0], sp.camPos[1], sp.camPos[2]);
+    const V3 facing = mk(sp.camFacing[0], sp.camFacing[1], sp.camFacing[2]);
+    const float resx = (float)sp.width, resy = (float)sp.height;
+    const float nresx = (float)sp.noiseW, nresy = (float)sp.noiseH;
+    const float vpH = sp.vpW * (resy / resx);                                   // F:145
+    const V3 U = normalize3(cross3(facing, mk(0.0f, 0.0f, 1.0f)));              // F:147
+    const V3 Vd = normalize3(cross3(U, facing));                                // F:148
     const uint32_t nTiles = sp.tilesX * sp.tilesY;
-    const uint32_t tx = tile % sp.tilesX, ty = tile / sp.tilesX;
-    const uint32_t px = tx * kTile + (lane & 7u), py = ty * kTile + (lane >> 3);
-    const bool valid = tile < nTiles && px < sp.width && py < sp.height;
-    uint2* stack = lds_stack + lane;
-    const size_t slot = (size_t)localTile * 64 + lane;
+
+    // Groups of consecutive tiles are queued in 8 bands; a wave drains the band with its
+    // blockIdx % 8 label first (waves with equal labels share an XCD, hence an L2), then helps
+    // the other bands. Which band a wave starts on only affects speed.
+    const uint32_t bandSize = (nGroups + 7u) / 8u;
+    uint32_t band = blockIdx.x % 8u, bandsTried = 0;
+    uint32_t poolNext = 0, poolEnd = 0;       // wave-uniform: slots [poolNext, poolEnd) wait for a lane
+    bool queueEmpty = false;
 
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (valid) {
-        const uint32_t BL = sp.bounceLimit;
-        const V3 camPos = mk(sp.camPos[0], sp.camPos[1], sp.camPos[2]);
-        const V3 facing = mk(sp.camFacing[0], sp.camFacing[1], sp.camFacing[2]);
-        const float resx = (float)sp.width, resy = (float)sp.height;
-        const float nresx = (float)sp.noiseW, nresy = (float)sp.noiseH;
-        // F:144-148
-        const float vpH = sp.vpW * (resy / resx);
-        const V3 U = normalize3(cross3(facing, mk(0.0f, 0.0f, 1.0f)));
-        const V3 Vd = normalize3(cross3(U, facing));
-        const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    Lane L;
+    L.state = kIdle; L.slot = 0; L.k = 0; L.bounce = 0; L.segments = 0; L.cur = kNoRef; L.top = 0;
+    L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0;
+    L.previous = mk(0.f, 0.f, 0.f); L.throughput = mk(1.f, 1.f, 1.f);
+    L.ray.o = L.ray.d = L.ray.inv = mk(0.f, 0.f, 0.f);
+    V3 hitNormal = mk(0.0f, 0.0f, 0.0f);      // hitRecord.normal persists across bounces of a path (F:381)
 
-        float4 acc = IDS ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[slot];
-        V3 previous = mk(acc.x, acc.y, acc.z);
-        uint32_t k = 0;                 // frame counter of this lane
-        FrameParams fp = frames[0];
-        Path p;
-        bool fresh = true;              // start a new path before the next traversal
-        uint32_t segments = 0;          // traversals of the current path (bounded by kMaxSegments)
-        V3 hitNormal = mk(0.0f, 0.0f, 0.0f);   // hitRecord.normal persists across bounces (F:381)
-        V3 hitColour = mk(0.0f, 0.0f, 0.0f);   // hitRecord.material.colour likewise
-        for (;;) {
-            if (fresh) {
+    for (;;) {
+        // ---- hand waiting pixels to idle lanes ----
+        unsigned long long idleMask = __ballot(L.state == kIdle);
+        if (idleMask != 0ull) {
+            if (poolNext == poolEnd && !queueEmpty) {
+                // pull the next group of tiles: one returning atomic by lane 0, broadcast to the wave
+                for (;;) {
+                    uint32_t g = 0;
+                    if (lane == 0) g = atomicAdd(&queueHeads[band], 1u);
+                    g = __builtin_amdgcn_readfirstlane(g);
+                    const uint32_t first = band * bandSize;
+                    const uint32_t last = min(first + bandSize, nGroups);
+                    if (first + g < last) {
+                        poolNext = (first + g) * tilesPerGroup * 64u;
+                        poolEnd = min(poolNext + tilesPerGroup * 64u, sp.shardTiles * 64u);
+                        break;
+                    }
+                    band = (band + 1u) % 8u;
+                    if (++bandsTried >= 8u) { queueEmpty = true; break; }
+                }
+            }
+            if (poolNext != poolEnd && L.state == kIdle) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+                const uint32_t s = poolNext + rank;
+                if (s < poolEnd) {
+                    const uint32_t tile = (s >> 6) * sp.shardWorld + sp.shardRank;
+                    const uint32_t inTile = s & 63u;
+                    const uint32_t px = (tile % sp.tilesX) * kTile + (inTile & 7u), py = (tile / sp.tilesX) * kTile + (inTile >> 3);
+                    if (tile < nTiles && px < sp.width && py < sp.height) {
+                        L.slot = s; L.k = 0;
+                        float4 acc = IDS ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[s];
+                        L.previous = mk(acc.x, acc.y, acc.z);
+                        L.state = kNewPath;
+                    }
+                }
+            }
+            if (poolNext != poolEnd) poolNext = min(poolEnd, poolNext + (uint32_t)__popcll(idleMask));
+        }
+
+        // ---- pick the most populated state (ballot + popcount, wave-uniform) ----
+        const int nNew = __popcll(__ballot(L.state == kNewPath));
+        const int nInt = __popcll(__ballot(L.state == kInterior));
+        const int nLeaf = __popcll(__ballot(L.state == kLeaf));
+        const int nShade = __popcll(__ballot(L.state == kShade));
+        if ((nNew | nInt | nLeaf | nShade) == 0) {
+            if (queueEmpty && poolNext == poolEnd) break;      // every wave reaches this: the queues only shrink
+            continue;
+        }
+        const int most = max(max(nNew, nInt), max(nLeaf, nShade));
+
+        if (nInt == most) {
+            // the hot loop: stay in it while most of the lanes that entered are still descending
+            int steps = 0;
+            do {
+                if (L.state == kInterior) interior_step<COUNT>(sp, st, L, tl);
+                ++steps;
+            } while (steps < 8 && __popcll(__ballot(L.state == kInterior)) * 4 >= nInt * 3);
+        } else if (nLeaf == most) {
+            if (L.state == kLeaf) leaf_step<COUNT>(sp, st, L, tl);
+        } else if (nNew == most) {
+            if (L.state == kNewPath) {
                 // F:461-462: per-frame jitter from the noise texture, primary ray
+                const FrameParams fp = frames[L.k];
+                const uint32_t tile = (L.slot >> 6) * sp.shardWorld + sp.shardRank, inTile = L.slot & 63u;
+                const float fx = (float)((tile % sp.tilesX) * kTile + (inTile & 7u)) + 0.5f;
+                const float fy = (float)((tile / sp.tilesX) * kTile + (inTile >> 3)) + 0.5f;
                 if (COUNT) tl.noise++;
                 V3 ro = sample_noise(sp, fp.seedY + 0.007f * 0.0f, fp.seedZ + 0.007f * 0.0f);
                 V3 pt = ((camPos + sp.vpD * facing) + (sp.vpW * (-0.5f + ((fx - 0.5f) + ro.x) / resx)) * U) +
                         (vpH * (-0.5f + ((fy - 0.5f) + ro.y) / resy)) * Vd;
-                p.ray = MakeRay(camPos, normalize3(pt - camPos));
-                p.throughput = mk(1.0f, 1.0f, 1.0f);
-                p.bounce = 0;
-                segments = 0;
-                hitNormal = mk(0.0f, 0.0f, 0.0f);      // a new invocation starts with a blank hit record
-                hitColour = mk(0.0f, 0.0f, 0.0f);
-                fresh = false;
+                L.ray = MakeRay(camPos, normalize3(pt - camPos));
+                L.throughput = mk(1.0f, 1.0f, 1.0f);
+                L.bounce = 0; L.segments = 0;
+                hitNormal = mk(0.0f, 0.0f, 0.0f);          // a new invocation starts with a blank hit record
+                begin_traversal<COUNT>(sp, L, tl);
             }
-            Hit hit; int iters;
-            traverse<STACK, COUNT>(sp, p.ray, stack, hit, iters, tl);
-            if (IDS) {
-                ids[slot * 3 + 0] = hit.index; ids[slot * 3 + 1] = (int32_t)__float_as_uint(hit.t); ids[slot * 3 + 2] = iters;
-                break;
-            }
-            const bool hitAnything = hit.index >= 0;
-            if (COUNT && hitAnything) tl.hits++;
-            V3 hitPoint = mk(0.0f, 0.0f, 0.0f);
-            bool frontFace = false;
-            MaterialRec m;
-            if (hitAnything) {
-                // the part of hitTriangle that only the accepted hit needs (F:235-238) + material (F:291)
-                const float4* T = reinterpret_cast<const float4*>(sp.tris + hit.index);
-                float4 a = T[0], b4 = T[1], c = T[2];
-                V3 e1 = mk(a.w, b4.x, b4.y), e2 = mk(b4.z, b4.w, c.x);
-                hitPoint = p.ray.o + (1.0f * hit.t) * p.ray.d;
-                V3 n = normalize3(cross3(e1, e2));
-                frontFace = dot3(p.ray.d, n) < 0.0f;
-                hitNormal = frontFace ? n : -n;
-                m = sp.materials[__float_as_int(c.y)];
-                hitColour = mk(m.colour[0], m.colour[1], m.colour[2]);
-            }
-            bool done = false;          // path finished with colour `result`
-            V3 result = mk(0.0f, 0.0f, 0.0f);
-            if (BL == 0u) {
-                // BVH heat map, F:313-324,386-387
-                const float itf = (float)iters;
-                if (iters < 64) { float g = (1.0f / 64.0f) * itf; result = mk(g, g, g); }
-                else if (iters < 128) { float kk = (float)(iters - 64); result = mk(1.0f - (0.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk); }
-                else { float kk = (float)(iters - 128); result = mk(1.0f - (1.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk); }
-                done = true;
-            } else if (BL == 1u) {
-                result = abs3(hitNormal);                       // F:388-389
-                done = true;
-            } else {
-                const int i = p.bounce;
-                // F:391-394
-                uint32_t sx = Hashf(p.ray.o.x + p.ray.d.y) + Hash((uint32_t)i) + fp.hashX;
-                uint32_t sy = Hashf(p.ray.o.y + p.ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
-                float fsx = (float)sx, fsy = (float)sy;
-                float seedx = (fsx - nresx * floorf(fsx / nresx)) / nresx;
-                float seedy = (fsy - nresy * floorf(fsy / nresy)) / nresy;
-                if (!hitAnything) {
-                    if (COUNT) tl.sky += (i == 0) ? 2u : 1u;
-                    result = p.throughput * sample_sky(sp, p.ray.d);     // F:410-413
-                    done = true;
-                } else if (m.isLight) {
-                    result = (p.throughput * hitColour) * m.transparency;   // F:415-418
-                    done = true;
+        } else {
+            if (L.state == kShade) {
+                if (COUNT) tl.pops += (uint32_t)L.iters;
+                if (IDS) {
+                    ids[(size_t)L.slot * 3 + 0] = L.bestIdx; ids[(size_t)L.slot * 3 + 1] = (int32_t)__float_as_uint(L.bestT);
+                    ids[(size_t)L.slot * 3 + 2] = L.iters;
+                    L.state = kIdle;
                 } else {
-                    V3 next;
-                    int ii = i;
-                    if (COUNT) tl.noise++;
-                    float trRng = sample_noise(sp, seedx + 0.01534f, seedy + 0.183f).x;   // F:420
-                    if (trRng < m.transparency) {
-                        // TransparentScatter, F:328-336
-                        const float AIR = 1.0003f;
-                        float ri = frontFace ? AIR / m.refractionIndex : m.refractionIndex / AIR;
-                        float cos_theta = fminf(dot3(-p.ray.d, hitNormal), 1.0f);
-                        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-                        next = (ri * sin_theta <= 1.0f) ? refract3(p.ray.d, hitNormal, ri) : reflect3(p.ray.d, hitNormal);
-                        if (trRng < 0.5f) ii--;
-                    } else {
-                        if (COUNT) tl.noise += 2;
-                        V3 n3 = sample_noise(sp, seedx - 0.062f, seedy - 0.0345f);       // F:426
-                        V3 diffuseDir = normalize3(hitNormal + ((2.0f * n3) - mk(1.0f, 1.0f, 1.0f)) * m.roughness);
-                        V3 specularDir = reflect3(p.ray.d, hitNormal);
-                        bool isSpecular = sample_noise(sp, seedx, seedy).y < (1.0f - m.roughness);   // F:428
-                        specularDir = mix3(specularDir, diffuseDir, m.roughness);
-                        next = isSpecular ? specularDir : diffuseDir;
-                        V3 spec = mk(m.specular[0], m.specular[1], m.specular[2]);
-                        p.throughput = p.throughput * (isSpecular ? mix3(spec, hitColour, m.metallic) : hitColour);
+                    const FrameParams fp = frames[L.k];
+                    const bool hitAnything = L.bestIdx >= 0;
+                    if (COUNT && hitAnything) tl.hits++;
+                    V3 hitPoint = mk(0.0f, 0.0f, 0.0f), hitColour = mk(0.0f, 0.0f, 0.0f);
+                    bool frontFace = false;
+                    MaterialRec m;
+                    if (hitAnything) {
+                        // the part of hitTriangle that only the accepted hit needs (F:235-238) + material (F:291)
+                        const float4* T = reinterpret_cast<const float4*>(sp.tris + L.bestIdx);
+                        float4 a = T[0], b4 = T[1], c = T[2];
+                        V3 e1 = mk(a.w, b4.x, b4.y), e2 = mk(b4.z, b4.w, c.x);
+                        hitPoint = L.ray.o + (1.0f * L.bestT) * L.ray.d;
+                        V3 n = normalize3(cross3(e1, e2));
+                        frontFace = dot3(L.ray.d, n) < 0.0f;
+                        hitNormal = frontFace ? n : -n;
+                        m = sp.materials[__float_as_int(c.y)];
+                        hitColour = mk(m.colour[0], m.colour[1], m.colour[2]);
                     }
-                    p.ray = MakeRay(hitPoint + 1e-4f * next, next);         // F:433
-                    // adaptive early-out against the accumulated pixel, F:435-446
-                    V3 diff = abs3(p.throughput - previous);
-                    float distance = (diff.x + diff.y) + diff.z;
-                    int inc = (int)(BL / 4u);
-                    if (distance < 1.0f) ii += inc;
-                    if (distance < 0.4f) ii += inc;
-                    if (distance < 0.2f) ii += inc;
-                    ii++;                                                   // ++i of the for statement
-                    p.bounce = ii;
-                    ++segments;
-                    // F:384,448; plus a bound on free glass bounces so that every wave is sure to finish
-                    if (!((uint32_t)ii <= BL) || segments >= kMaxSegments) { result = mk(0.0f, 0.0f, 0.0f); done = true; }
+                    bool done = false;          // path finished with colour `result`
+                    V3 result = mk(0.0f, 0.0f, 0.0f);
+                    if (BL == 0u) {
+                        // BVH heat map, F:313-324,386-387
+                        const int iters = L.iters;
+                        const float itf = (float)iters;
+                        if (iters < 64) { float g = (1.0f / 64.0f) * itf; result = mk(g, g, g); }
+                        else if (iters < 128) { float kk = (float)(iters - 64); result = mk(1.0f - (0.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk); }
+                        else { float kk = (float)(iters - 128); result = mk(1.0f - (1.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk); }
+                        done = true;
+                    } else if (BL == 1u) {
+                        result = abs3(hitNormal);                       // F:388-389
+                        done = true;
+                    } else {
+                        const int i = L.bounce;
+                        // F:391-394
+                        uint32_t sx = Hashf(L.ray.o.x + L.ray.d.y) + Hash((uint32_t)i) + fp.hashX;
+                        uint32_t sy = Hashf(L.ray.o.y + L.ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
+                        float fsx = (float)sx, fsy = (float)sy;
+                        float seedx = (fsx - nresx * floorf(fsx / nresx)) / nresx;
+                        float seedy = (fsy - nresy * floorf(fsy / nresy)) / nresy;
+                        if (!hitAnything) {
+                            if (COUNT) tl.sky += (i == 0) ? 2u : 1u;
+                            result = L.throughput * sample_sky(sp, L.ray.d);     // F:410-413
+                            done = true;
+                        } else if (m.isLight) {
+                            result = (L.throughput * hitColour) * m.transparency;   // F:415-418
+                            done = true;
+                        } else {
+                            V3 next;
+                            int ii = i;
+                            if (COUNT) tl.noise++;
+                            float trRng = sample_noise(sp, seedx + 0.01534f, seedy + 0.183f).x;   // F:420
+                            if (trRng < m.transparency) {
+                                // TransparentScatter, F:328-336
+                                const float AIR = 1.0003f;
+                                float ri = frontFace ? AIR / m.refractionIndex : m.refractionIndex / AIR;
+                                float cos_theta = fminf(dot3(-L.ray.d, hitNormal), 1.0f);
+                                float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                                next = (ri * sin_theta <= 1.0f) ? refract3(L.ray.d, hitNormal, ri) : reflect3(L.ray.d, hitNormal);
+                                if (trRng < 0.5f) ii--;
+                            } else {
+                                if (COUNT) tl.noise += 2;
+                                V3 n3 = sample_noise(sp, seedx - 0.062f, seedy - 0.0345f);       // F:426
+                                V3 diffuseDir = normalize3(hitNormal + ((2.0f * n3) - mk(1.0f, 1.0f, 1.0f)) * m.roughness);
+                                V3 specularDir = reflect3(L.ray.d, hitNormal);
+                                bool isSpecular = sample_noise(sp, seedx, seedy).y < (1.0f - m.roughness);   // F:428
+                                specularDir = mix3(specularDir, diffuseDir, m.roughness);
+                                next = isSpecular ? specularDir : diffuseDir;
+                                V3 spec = mk(m.specular[0], m.specular[1], m.specular[2]);
+                                L.throughput = L.throughput * (isSpecular ? mix3(spec, hitColour, m.metallic) : hitColour);
+                            }
+                            L.ray = MakeRay(hitPoint + 1e-4f * next, next);         // F:433
+                            // adaptive early-out against the accumulated pixel, F:435-446
+                            V3 diff = abs3(L.throughput - L.previous);
+                            float distance = (diff.x + diff.y) + diff.z;
+                            int inc = (int)(BL / 4u);
+                            if (distance < 1.0f) ii += inc;
+                            if (distance < 0.4f) ii += inc;
+                            if (distance < 0.2f) ii += inc;
+                            ii++;                                                   // ++i of the for statement
+                            L.bounce = ii;
+                            ++L.segments;
+                            // F:384,448; plus a bound on free glass bounces so that every wave is sure to finish
+                            if (!((uint32_t)ii <= BL) || L.segments >= kMaxSegments) { result = mk(0.0f, 0.0f, 0.0f); done = true; }
+                            else begin_traversal<COUNT>(sp, L, tl);
+                        }
+                    }
+                    if (done) {
+                        // F:480-487
+                        V3 rgb = mk(0.0f, 0.0f, 0.0f) + result;
+                        rgb = rgb * (1.0f / 1.0f);
+                        L.previous = mix3(L.previous, rgb, fp.weight);
+                        if (COUNT) tl.paths++;
+                        ++L.k;
+                        if (L.k >= nFrames) {
+                            accum[L.slot] = make_float4(L.previous.x, L.previous.y, L.previous.z, 0.0f);
+                            L.state = kIdle;
+                        } else {
+                            L.state = kNewPath;
+                        }
+                    }
                 }
             }
-            if (done) {
-                // F:480-487
-                V3 rgb = mk(0.0f, 0.0f, 0.0f) + result;
-                rgb = rgb * (1.0f / 1.0f);
-                previous = mix3(previous, rgb, fp.weight);
-                tl.paths++;
-                ++k;
-                if (k >= nFrames) break;
-                fp = frames[k];
-                fresh = true;
-            }
         }
-        if (!IDS) accum[slot] = make_float4(previous.x, previous.y, previous.z, 0.0f);
     }
 
-    // per-tile tallies: the owning wave adds its sums (no atomics; one wave owns a tile)
+    // per-wave tallies: each wave owns one column (no atomics)
     uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths, tl.hits};
-    const int nSlots = COUNT ? (int)kCounterSlots : 1;
-    for (int s = 0; s < nSlots; ++s) {
-        uint32_t v = (s == 0 || COUNT) ? vals[s] : 0u;
+    for (int s = 0; s < (int)kCounterSlots; ++s) {
+        if (!COUNT && s != (int)kRays) continue;
+        uint32_t v = vals[s];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0 && tile < nTiles) tally[(size_t)s * sp.shardTiles + localTile] += v;
+        if (lane == 0) tally[(size_t)s * tallyStride + blockIdx.x] += v;
     }
 }
 
@@ -439,25 +537,31 @@ __global__ void untile_kernel(const float4* __restrict__ tiled, float4* __restri
 
 }  // namespace
 
+
 // ---- launchers used by rt_api.cpp ----
 namespace rtd {
 
-template <int STACK>
-static void launch_stack(bool count, bool ids, hipStream_t st, uint32_t nBlocks, const SceneParams& sp, const FrameParams* frames,
-                         uint32_t nFrames, float4* accum, uint32_t* tally, int32_t* idsOut) {
-    dim3 grid(nBlocks), block(64);
-    if (ids) hipLaunchKernelGGL((trace_kernel<STACK, true, true>), grid, block, 0, st, sp, frames, nFrames, accum, tally, idsOut, nBlocks);
-    else if (count) hipLaunchKernelGGL((trace_kernel<STACK, true, false>), grid, block, 0, st, sp, frames, nFrames, accum, tally, idsOut, nBlocks);
-    else hipLaunchKernelGGL((trace_kernel<STACK, false, false>), grid, block, 0, st, sp, frames, nFrames, accum, tally, idsOut, nBlocks);
+uint32_t SpillEntriesPerWave() { return (uint32_t)(kMaxStack - kLdsStack) * 64u; }
+
+// Number of waves that can be resident at once on the current device (the persistent grid size).
+uint32_t ResidentWaves() {
+    int dev = 0, cus = 0, perCu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false>, 64, 0) != hipSuccess) return 0;
+    if (perCu < 1) perCu = 1;
+    return (uint32_t)cus * (uint32_t)perCu;
 }
 
-// stackEntries must be 16, 32 or 64.
-void LaunchTrace(int stackEntries, bool count, bool ids, hipStream_t st, uint32_t nBlocks, const SceneParams& sp, const FrameParams* frames,
-                 uint32_t nFrames, void* accum, uint32_t* tally, int32_t* idsOut) {
+void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
+                 void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
+                 uint32_t tilesPerGroup) {
     float4* a = static_cast<float4*>(accum);
-    if (stackEntries <= 16) launch_stack<16>(count, ids, st, nBlocks, sp, frames, nFrames, a, tally, idsOut);
-    else if (stackEntries <= 32) launch_stack<32>(count, ids, st, nBlocks, sp, frames, nFrames, a, tally, idsOut);
-    else launch_stack<64>(count, ids, st, nBlocks, sp, frames, nFrames, a, tally, idsOut);
+    uint2* sa = static_cast<uint2*>(spillArea);
+    dim3 grid(nWaves), block(64);
+    if (ids) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride);
+    else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride);
 }
 
 void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots) {
