@@ -220,7 +220,9 @@ def main():
                     "algorithmic_bytes_per_launch": int(per_launch),
                     "bytes_per_ray": round(algorithmic_bytes(ci) / ci["rays"], 1),
                     "boxes_per_ray": round(ci["boxes_tested"] / ci["rays"], 2),
-                    "tris_per_ray": round(ci["tris_tested"] / ci["rays"], 2)}
+                    "tris_per_ray": round(ci["tris_tested"] / ci["rays"], 2),
+                    "lane_use_new_interior_leaf_shade": [round(l / (64.0 * max(1, n)), 3) for l, n in zip(ci["sched_lanes"], ci["sched_rounds"])],
+                    "rounds_new_interior_leaf_shade": [n // launches for n in ci["sched_rounds"]]}
 
     if rank == 0:
         out = {

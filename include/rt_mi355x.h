@@ -69,6 +69,10 @@ typedef struct rt_counters {
     uint64_t sky_fetches;    /* texture(u_Skybox, ...) calls */
     uint64_t paths;          /* pixel samples finished */
     uint64_t hits;           /* rays that hit a triangle (full counting only) */
+    /* wave scheduler statistics (full counting only), per lane state new-path / interior / leaf / shade:
+     * rounds a wave spent in that state's code, and how many of its 64 lanes took part */
+    uint64_t sched_rounds[4];
+    uint64_t sched_lanes[4];
 } rt_counters;
 
 /* Library-level message for failures that happen before a context exists (rt_create). */

@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_mi355x.so")
+LIB_PATH = os.environ.get("RT_LIB_PATH") or os.path.join(_HERE, "librt_mi355x.so")   # RT_LIB_PATH: kernel-tuning experiments only
 
 
 class rt_material(ctypes.Structure):
@@ -22,7 +22,8 @@ class rt_camera(ctypes.Structure):
 
 class rt_counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches",
-                                               "sky_fetches", "paths", "hits")]
+                                               "sky_fetches", "paths", "hits")] + [("sched_rounds", ctypes.c_uint64 * 4),
+                                                                                    ("sched_lanes", ctypes.c_uint64 * 4)]
 
 
 class rth_bvh_stats(ctypes.Structure):

@@ -480,6 +480,7 @@ int rt_get_counters(rt_context* c, rt_counters* out, int reset) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->rays = t[kRays]; out->node_pops = t[kPops]; out->boxes_tested = t[kBoxes]; out->tris_tested = t[kTris];
     out->noise_fetches = t[kNoise]; out->sky_fetches = t[kSky]; out->paths = t[kPaths] + c->hostPaths; out->hits = t[kHits];
+    for (int k = 0; k < 4; ++k) { out->sched_rounds[k] = t[kRoundsNew + k]; out->sched_lanes[k] = t[kLanesNew + k]; }
     if (reset) c->hostPaths = 0;
     if (reset) HIP_TRY(c, hipMemsetAsync(c->dTotals, 0, sizeof t, c->stream));
     return RT_OK;

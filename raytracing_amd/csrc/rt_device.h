@@ -87,6 +87,9 @@ struct FrameParams {
     uint32_t frameIndex;
 };
 
-enum CounterSlot { kRays = 0, kPops, kBoxes, kTris, kNoise, kSky, kPaths, kHits, kCounterSlots };
+enum CounterSlot { kRays = 0, kPops, kBoxes, kTris, kNoise, kSky, kPaths, kHits,
+                   kRoundsNew, kRoundsInterior, kRoundsLeaf, kRoundsShade,   // scheduler rounds run per state (per wave)
+                   kLanesNew, kLanesInterior, kLanesLeaf, kLanesShade,       // lanes that took part in those rounds
+                   kCounterSlots };
 
 }  // namespace rtd

@@ -149,11 +149,32 @@ __device__ __forceinline__ bool hit_box(const Ray& r, float mnx, float mny, floa
 }
 
 
-struct Tally { uint32_t rays, pops, boxes, tris, noise, sky, paths, hits; };
+struct Tally { uint32_t rays, pops, boxes, tris, noise, sky, paths, hits; uint32_t rounds[4]; uint32_t lanes[4]; };
 
 enum LaneState : int { kIdle = 0, kNewPath = 1, kInterior = 2, kLeaf = 3, kShade = 4 };
 
-constexpr int kLdsStack = 16;          // stack entries per lane kept in LDS (8 KiB per wave)
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 16
+#endif
+#ifndef RT_INT_STEPS
+#define RT_INT_STEPS 8
+#endif
+#ifndef RT_KEEP_NUM
+#define RT_KEEP_NUM 3
+#endif
+#ifndef RT_KEEP_DEN
+#define RT_KEEP_DEN 4
+#endif
+#ifndef RT_LEAF_AT
+#define RT_LEAF_AT 64      // run the leaf code as soon as this many lanes wait for it (64 = only when it is the biggest group)
+#endif
+#ifndef RT_SHADE_AT
+#define RT_SHADE_AT 64
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 5
+#endif
+constexpr int kLdsStack = RT_LDS_STACK;   // stack entries per lane kept in LDS (512 B per entry per wave)
 
 // Everything a lane carries between scheduler rounds.
 struct Lane {
@@ -173,13 +194,17 @@ struct Lane {
 };
 
 struct StackRef {
-    uint2* lds;             // this lane's LDS column, stride 64
-    uint2* spill;           // this lane's HBM column, stride 64 (entries kLdsStack .. kMaxStack-1)
+    uint2* lds;                 // this lane's LDS column, stride 64 entries
+    unsigned long long* spill;  // this lane's HBM column, stride 64 (entries kLdsStack .. kMaxStack-1)
 };
 
+// The two halves of the stack are accessed with different value types on purpose: with equal
+// types the compiler merges the LDS and the HBM access into one FLAT instruction on a selected
+// pointer, which is slower than ds_read/ds_write and drags the LDS traffic through the vector
+// memory path.
 __device__ __forceinline__ void push(const StackRef& st, int& top, uint32_t ref, float t) {
-    uint2 e = make_uint2(ref, __float_as_uint(t));
-    if (top < kLdsStack) st.lds[top * 64] = e; else st.spill[(top - kLdsStack) * 64] = e;
+    if (top < kLdsStack) st.lds[top * 64] = make_uint2(ref, __float_as_uint(t));
+    else st.spill[(top - kLdsStack) * 64] = ((unsigned long long)__float_as_uint(t) << 32) | ref;
     ++top;
 }
 
@@ -190,7 +215,11 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
     for (;;) {
         if (L.top == 0) { L.cur = kNoRef; L.state = kShade; return; }
         --L.top;
-        uint2 e = (L.top < kLdsStack) ? st.lds[L.top * 64] : st.spill[(L.top - kLdsStack) * 64];
+        uint2 e = st.lds[min(L.top, kLdsStack - 1) * 64];
+        if (L.top >= kLdsStack) {
+            unsigned long long w = st.spill[(L.top - kLdsStack) * 64];
+            e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+        }
         L.iters++;
         if (__uint_as_float(e.y) >= L.bestT) continue;
         L.cur = e.x;
@@ -267,7 +296,7 @@ __device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef&
 }
 
 template <bool COUNT, bool IDS>
-__global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
+__global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
                                                    float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
                                                    int32_t* __restrict__ ids /* IDS only: [slot][3] */,
                                                    uint2* __restrict__ spillArea /* [gridDim.x][kMaxStack-kLdsStack][64] */,
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
     const uint32_t lane = threadIdx.x;
     StackRef st;
     st.lds = lds_stack + lane;
-    st.spill = spillArea + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64 + lane;
+    st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64 + lane;
 
     const uint32_t BL = sp.bounceLimit;
     const V3 camPos = mk(sp.camPos[0], sp.camPos[1], sp.camPos[2]);
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
     uint32_t poolNext = 0, poolEnd = 0;       // wave-uniform: slots [poolNext, poolEnd) wait for a lane
     bool queueEmpty = false;
 
-    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
     Lane L;
     L.state = kIdle; L.slot = 0; L.k = 0; L.bounce = 0; L.segments = 0; L.cur = kNoRef; L.top = 0;
     L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0;
@@ -354,17 +383,21 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
             continue;
         }
         const int most = max(max(nNew, nInt), max(nLeaf, nShade));
+        const bool runShade = nShade >= RT_SHADE_AT, runLeaf = !runShade && nLeaf >= RT_LEAF_AT;
 
-        if (nInt == most) {
+        if (nInt == most && !runShade && !runLeaf) {
             // the hot loop: stay in it while most of the lanes that entered are still descending
             int steps = 0;
             do {
+                if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += (L.state == kInterior); }
                 if (L.state == kInterior) interior_step<COUNT>(sp, st, L, tl);
                 ++steps;
-            } while (steps < 8 && __popcll(__ballot(L.state == kInterior)) * 4 >= nInt * 3);
-        } else if (nLeaf == most) {
+            } while (steps < RT_INT_STEPS && __popcll(__ballot(L.state == kInterior)) * RT_KEEP_DEN >= nInt * RT_KEEP_NUM);
+        } else if (runLeaf || (nLeaf == most && !runShade)) {
+            if (COUNT) { tl.rounds[2] += (lane == 0); tl.lanes[2] += (L.state == kLeaf); }
             if (L.state == kLeaf) leaf_step<COUNT>(sp, st, L, tl);
-        } else if (nNew == most) {
+        } else if (nNew == most && !runShade) {
+            if (COUNT) { tl.rounds[0] += (lane == 0); tl.lanes[0] += (L.state == kNewPath); }
             if (L.state == kNewPath) {
                 // F:461-462: per-frame jitter from the noise texture, primary ray
                 const FrameParams fp = frames[L.k];
@@ -382,6 +415,7 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
                 begin_traversal<COUNT>(sp, L, tl);
             }
         } else {
+            if (COUNT) { tl.rounds[3] += (lane == 0); tl.lanes[3] += (L.state == kShade); }
             if (L.state == kShade) {
                 if (COUNT) tl.pops += (uint32_t)L.iters;
                 if (IDS) {
@@ -495,7 +529,8 @@ __global__ __launch_bounds__(64) void trace_kernel(SceneParams sp, const FramePa
     }
 
     // per-wave tallies: each wave owns one column (no atomics)
-    uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths, tl.hits};
+    uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths, tl.hits,
+                                    tl.rounds[0], tl.rounds[1], tl.rounds[2], tl.rounds[3], tl.lanes[0], tl.lanes[1], tl.lanes[2], tl.lanes[3]};
     for (int s = 0; s < (int)kCounterSlots; ++s) {
         if (!COUNT && s != (int)kRays) continue;
         uint32_t v = vals[s];

@@ -190,7 +190,8 @@ class Renderer:
     def counters(self, reset=False):
         c = rt_counters()
         self._ck(self.L.rt_get_counters(self.h, ctypes.byref(c), int(reset)), "rt_get_counters")
-        return {f: int(getattr(c, f)) for f, _ in rt_counters._fields_}
+        return {f: (int(getattr(c, f)) if not hasattr(getattr(c, f), "__len__") else [int(v) for v in getattr(c, f)])
+                for f, _ in rt_counters._fields_}
 
     def set_counting(self, full):
         self._ck(self.L.rt_set_counting(self.h, int(full)), "rt_set_counting")
