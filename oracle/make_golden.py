@@ -184,7 +184,7 @@ def bvh_fixtures(ref):
         r = ref.build(tri9, mat)
         out[name + "_in_tri9"], out[name + "_in_mat"] = tri9, mat
         out[name + "_tri12"], out[name + "_matidx"], out[name + "_node8"] = r["tri12"], r["matidx"], r["node8"]
-        out[name + "_log"] = r["log"]
+        out[name + "_log"] = "\n".join(l for l in r["log"].splitlines() if "took:" not in l)   # drop the timing line
     out["manifest"] = "reference BvhTree.cpp/ObjectLoader.h compiled with g++ -O3 (oracle/Makefile); generator oracle/make_golden.py"
     np.savez_compressed(os.path.join(GOLD, "bvh_reference.npz"), **out)
     print("bvh_reference: %d cases" % len(cases))
@@ -225,10 +225,48 @@ def loader_fixtures(ref):
         # the reference numbers materials with a process-wide counter; rebase to this scene
         out[g + "_matidx_rebased"] = r["matidx"] - base
         out[g + "_mats11"] = r["mats11"]
-        out[g + "_log"] = r["log"]
+        out[g + "_log"] = "\n".join(l for l in r["log"].splitlines() if "took:" not in l)
         print("loader %s: %d tris, %d materials, first slot %d" % (g, len(r["matidx"]), len(r["mats11"]) // 11, r["first_slot"]))
     out["manifest"] = "reference ObjectLoader.h/BvhTree.cpp compiled with g++ -O3; object files written by oracle/make_golden.py"
     np.savez_compressed(os.path.join(GOLD, "loader_reference.npz"), **out)
+
+
+def boundary_safe_hdr(W, H, seed):
+    """HDR test image that is constant on 5x5 blocks offset by 2 pixels. The reference's NEAREST
+    down-blits sample exactly on texel boundaries for the even factors (10, 20, 40): which of the two
+    neighbouring texels llvmpipe then takes is rounding noise of its interpolator. On this image both
+    candidates always carry the same value, so the whole chain is comparable."""
+    r = np.random.default_rng(seed)
+    bw, bh = (W + 3) // 5 + 1, (H + 3) // 5 + 1
+    base = (r.random((bh, bw, 3)) * 0.9).astype(f32)
+    yy, xx = np.mgrid[0:bh, 0:bw]
+    for _ in range(10):
+        cx, cy = r.integers(0, bw), r.integers(0, bh)
+        rad = r.integers(1, max(2, bw // 8))
+        base[((xx - cx) ** 2 + (yy - cy) ** 2) <= rad * rad] = r.uniform(1.2, 8.0, 3).astype(f32)
+    base[0, :4] = (0.0, 2.0, 0.0)            # a bright texel with zero channels: the 0/0 centre tap
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.zeros((H, W, 4), f32)
+    img[..., :3] = base[(yy + 3) // 5, (xx + 3) // 5]
+    return img
+
+
+def post_fixture(gl):
+    W, H = 160, 80
+    ref = ReferenceRenderer(W, H, gl=gl)
+    out = {"width": W, "height": H, "manifest": manifest(gl)}
+    for frame in range(3):                   # consecutive frames: the tmp texture carries over
+        a = boundary_safe_hdr(W, H, 40 + frame)
+        ref.write_accum(a)
+        rgba, rgb8 = ref.postprocess(True)
+        out["accum%d" % frame] = a
+        out["final%d" % frame] = rgba[..., :3].copy()
+        out["rgb8_%d" % frame] = rgb8
+        if frame == 2:
+            for i in range(4):
+                out["level%d_%d" % (i, frame)] = ref.level_image(i)[..., :3].copy()
+    np.savez_compressed(os.path.join(GOLD, "post_reference.npz"), **out)
+    print("post_reference: 3 frames %dx%d" % (W, H))
 
 
 def main():
@@ -252,6 +290,7 @@ def main():
     tracer_fixture(gl, "teapot_small", scene_from(scenes.teapot_like(target_tris=4000), tmp + "/d"), 70, 38, DEFAULT_CAMERA, noise, sky,
                    [(8, 8)])
     texture_fixture(gl)
+    post_fixture(gl)
     ref = RefHost()
     bvh_fixtures(ref)
     loader_fixtures(ref)

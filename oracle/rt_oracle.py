@@ -120,3 +120,36 @@ class Oracle:
         out = np.zeros(3, dtype=np.float32)
         self.L.orc_sample_sky(self.h, d.ctypes.data, out.ctypes.data)
         return out
+
+
+class PostOracle:
+    """CPU restatement of the bloom chain + final composite (post_oracle.cpp). Keeps the `tmp`
+    image between calls, as the reference does between frames."""
+
+    def __init__(self, width, height):
+        self.L = _load()
+        self.L.post_create.restype = ctypes.c_void_p
+        self.L.post_create.argtypes = [ctypes.c_int, ctypes.c_int]
+        self.L.post_destroy.argtypes = [ctypes.c_void_p]
+        self.L.post_run.argtypes = [ctypes.c_void_p] * 4
+        self.L.post_level.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        self.W, self.H = width, height
+        self.h = self.L.post_create(width, height)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.post_destroy(self.h)
+            self.h = None
+
+    def run(self, accum_rgba):
+        a = np.ascontiguousarray(accum_rgba, dtype=np.float32)
+        assert a.size == self.W * self.H * 4
+        rgba = np.empty((self.H, self.W, 4), dtype=np.float32)
+        rgb8 = np.empty((self.H, self.W, 3), dtype=np.uint8)
+        self.L.post_run(self.h, a.ctypes.data, rgba.ctypes.data, rgb8.ctypes.data)
+        return rgba, rgb8
+
+    def level(self, i):
+        out = np.empty((self.H, self.W, 3), dtype=np.float32)
+        self.L.post_level(self.h, i, out.ctypes.data)
+        return out

@@ -1,8 +1,23 @@
-// Post-processing kernels: bloom chain and final composite (placeholder build: raw path only).
+// Post-processing kernels for gfx950: the reference's bloom chain and final composite
+// (src/main.cpp:242-275 with extractBrightFragment.glsl = E:, bloomFragment.glsl = B:,
+// finalFragment.glsl = Fi:), plus the 8-bit read-back of Include/Recorder.h:93-100.
+//
+// The reference runs every pass over the whole window (it never calls glViewport), although only
+// a small corner of each pass is used afterwards, and its `tmp` texture carries pixels from one
+// level to the next and from one frame to the next. Here each pass is evaluated only on the
+// region later passes actually read (derived in Regions() below), which gives the same images:
+//   per level ds in {5,10,20,40}:   (levels 80 and 160 are computed by the reference but never read: Fi:10,26)
+//     down   tmp[0:w,0:h] <- nearest sample of the accumulation               main.cpp:244-248
+//     pre    threshold E:9-16 + per-texel half of the blur tap B:9-18,35      (whole needed region)
+//     blur   49-tap disc, B:20-46, LDS-tiled: a 40x16 texel tile feeds 32x8 outputs
+//     up     levels[i] <- bilinear up-blit of tmp[0:w,0:h]                    main.cpp:261-265
+//   final  tmp <- pow(accum, 1/1.61803) + levels[0..3]                        Fi:17-30
+// Nearest down-blit: the sample point of an even factor lies exactly on a texel boundary; the
+// texel at floor((x + 0.5) * W / w) is taken.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <string>
-#include <vector>
 
 #include "rt_device.h"
 #include "rt_mi355x.h"
@@ -10,47 +25,214 @@
 namespace rtd {
 
 namespace {
+
+constexpr int kLevels = 4;
+
+__global__ void down_kernel(const float4* __restrict__ accum, float4* __restrict__ tmp, int W, int H, int w, int h) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    int sx = (int)floorf(((float)x + 0.5f) * ((float)W / (float)w));
+    int sy = (int)floorf(((float)y + 0.5f) * ((float)H / (float)h));
+    sx = min(sx, W - 1); sy = min(sy, H - 1);
+    float4 s = accum[(size_t)sy * W + sx];
+    tmp[(size_t)y * W + x] = make_float4(s.x, s.y, s.z, 0.0f);
+}
+
+// E:9-16 then B:9-18 and the texel-only factors of B:35: out = (cc(rgb) * level) * 0.5, w = level >= 1.01
+__global__ void pre_kernel(const float4* __restrict__ tmp, float4* __restrict__ pre, int W, int rw, int rh) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= rw || y >= rh) return;
+    float4 s = tmp[(size_t)y * W + x];
+    float len = sqrtf((s.z * s.z + s.y * s.y) + s.x * s.x);
+    float c[3] = {0.0f, 0.0f, 0.0f};
+    if (len >= 1.5f) { c[0] = s.x; c[1] = s.y; c[2] = s.z; }
+    float level = fmaxf(c[0], fmaxf(c[1], c[2]));
+    if (level > 1.0f) {
+        float e = 1.0f / level;
+        for (int k = 0; k < 3; ++k) c[k] = powf(c[k] / level, e);
+    }
+    pre[(size_t)y * W + x] = make_float4((c[0] * level) * 0.5f, (c[1] * level) * 0.5f, (c[2] * level) * 0.5f, level >= 1.01f ? 1.0f : 0.0f);
+}
+
+constexpr int kBlurTX = 32, kBlurTY = 8, kApron = 4;
+constexpr int kTileW = kBlurTX + 2 * kApron, kTileH = kBlurTY + 2 * kApron;
+
+// B:20-46. One block = 32x8 outputs; the 40x16 texel neighbourhood is staged in LDS once
+// instead of being fetched 49 times per output.
+__global__ __launch_bounds__(kBlurTX* kBlurTY) void blur_kernel(const float4* __restrict__ pre, float4* __restrict__ tmp, int W, int H,
+                                                                  int preW, int preH, int rw, int rh) {
+    __shared__ float4 tile[kTileH][kTileW];
+    const int bx0 = blockIdx.x * kBlurTX, by0 = blockIdx.y * kBlurTY;
+    for (int i = threadIdx.y * kBlurTX + threadIdx.x; i < kTileW * kTileH; i += kBlurTX * kBlurTY) {
+        int lx = i % kTileW, ly = i / kTileW;
+        int gx = bx0 - kApron + lx, gy = by0 - kApron + ly;
+        // texelFetch outside the texture returns 0; `pre` is only valid on [0,preW) x [0,preH)
+        bool ok = gx >= 0 && gy >= 0 && gx < W && gy < H && gx < preW && gy < preH;
+        tile[ly][lx] = ok ? pre[(size_t)gy * W + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
+    if (x >= rw || y >= rh) return;
+    float col[3] = {0.0f, 0.0f, 0.0f};
+    int n = 1;
+    for (int dx = -4; dx <= 4; ++dx) {
+        for (int dy = -4; dy <= 4; ++dy) {
+            float fx = (float)dx, fy = (float)dy;
+            if (!(sqrtf(fy * fy + fx * fx) <= 4.0f)) continue;                 // B:31
+            // ivec2(pixel + coord) truncates toward zero: -0.5 -> 0, -1.5 -> -1 (B:33)
+            int sx = x + dx, sy = y + dy;
+            int tx = sx >= 0 ? sx : sx + 1, ty = sy >= 0 ? sy : sy + 1;
+            float4 p = tile[ty - by0 + kApron][tx - bx0 + kApron];
+            if (p.w != 0.0f) {
+                float cx = fx / 4.0f, cy = fy / 4.0f;
+                float len = sqrtf(cy * cy + cx * cx);
+                float v0 = p.x / len, v1 = p.y / len, v2 = p.z / len;          // centre tap divides by 0
+                col[0] += fminf(fmaxf(v0, 0.0f), 2.0f);                        // clamp; NaN (0/0) -> 0
+                col[1] += fminf(fmaxf(v1, 0.0f), 2.0f);
+                col[2] += fminf(fmaxf(v2, 0.0f), 2.0f);
+            }
+            n++;
+        }
+    }
+    float d = (float)(n > 1 ? n : 1);
+    tmp[(size_t)y * W + x] = make_float4(col[0] / d, col[1] / d, col[2] / d, 0.0f);
+}
+
+// GL_LINEAR up-blit of tmp[0:w,0:h] to the whole image; the filter footprint may reach one texel
+// beyond the corner (CLAMP_TO_EDGE acts at the texture edge, not at the source rectangle).
+__global__ void up_kernel(const float4* __restrict__ tmp, float4* __restrict__ level, int W, int H, int w, int h) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    float u = ((float)x + 0.5f) * ((float)w / (float)W) - 0.5f;
+    float v = ((float)y + 0.5f) * ((float)h / (float)H) - 0.5f;
+    float fu = floorf(u), fv = floorf(v);
+    float wx = u - fu, wy = v - fv;
+    int x0 = (int)fu, y0 = (int)fv, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1); y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
+    float4 a = tmp[(size_t)y0 * W + x0], b = tmp[(size_t)y0 * W + x1], c = tmp[(size_t)y1 * W + x0], d = tmp[(size_t)y1 * W + x1];
+    float4 o;
+    { float top = a.x + wx * (b.x - a.x), bot = c.x + wx * (d.x - c.x); o.x = top + wy * (bot - top); }
+    { float top = a.y + wx * (b.y - a.y), bot = c.y + wx * (d.y - c.y); o.y = top + wy * (bot - top); }
+    { float top = a.z + wx * (b.z - a.z), bot = c.z + wx * (d.z - c.z); o.z = top + wy * (bot - top); }
+    o.w = 0.0f;
+    level[(size_t)y * W + x] = o;
+}
+
+// Fi:17-30
+__global__ void final_kernel(const float4* __restrict__ accum, const float4* __restrict__ l0, const float4* __restrict__ l1,
+                             const float4* __restrict__ l2, const float4* __restrict__ l3, float4* __restrict__ tmp, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = accum[i];
+    const float g = 1.0f / 1.61803f;
+    float4 a = l0[i], b = l1[i], c = l2[i], d = l3[i];
+    float r = powf(s.x, g), gr = powf(s.y, g), bl = powf(s.z, g);
+    r += a.x; r += b.x; r += c.x; r += d.x;
+    gr += a.y; gr += b.y; gr += c.y; gr += d.y;
+    bl += a.z; bl += b.z; bl += c.z; bl += d.z;
+    tmp[i] = make_float4(r, gr, bl, 0.0f);
+}
+
 // glGetTexImage(GL_RGB, GL_UNSIGNED_BYTE) of a float texture: clamp to [0,1], scale by 255, round to nearest.
-__global__ void to_rgb8_kernel(const float4* __restrict__ img, uint8_t* __restrict__ out, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void to_rgb8_kernel(const float4* __restrict__ img, uint8_t* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = img[i];
     float v[3] = {p.x, p.y, p.z};
     for (int k = 0; k < 3; ++k) {
         float f = v[k];
         f = !(f > 0.0f) ? 0.0f : (f > 1.0f ? 1.0f : f);
-        out[(size_t)i * 3 + k] = (uint8_t)(int)rintf(f * 255.0f);
+        out[i * 3 + k] = (uint8_t)(int)rintf(f * 255.0f);
     }
 }
-struct PostScratch { uint8_t* rgb8 = nullptr; size_t n = 0; };
+
+struct PostScratch {
+    uint32_t W = 0, H = 0;
+    float4* tmp = nullptr;            // persists between calls, like the reference's tmp texture
+    float4* pre = nullptr;
+    float4* level[kLevels] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t* rgb8 = nullptr;
+};
+
+void Release(PostScratch* s) {
+    if (s->tmp) (void)hipFree(s->tmp);
+    if (s->pre) (void)hipFree(s->pre);
+    for (auto& l : s->level) if (l) (void)hipFree(l);
+    if (s->rgb8) (void)hipFree(s->rgb8);
+    *s = PostScratch();
+}
+
+// Region [0,R[i]) x [0,R'[i]) on which level i's blur output is needed:
+//   the up-blit reads the corner plus one texel of bleed; the next level's blur (over its own
+//   region) reads this level's output, as left-over tmp content, up to 4 texels further out.
+void Regions(int W, int H, int rw[kLevels], int rh[kLevels]) {
+    const int ds[kLevels] = {5, 10, 20, 40};
+    int needW = 0, needH = 0;
+    for (int i = kLevels - 1; i >= 0; --i) {
+        rw[i] = W / ds[i] + 1 > needW ? W / ds[i] + 1 : needW;
+        rh[i] = H / ds[i] + 1 > needH ? H / ds[i] + 1 : needH;
+        if (rw[i] > W) rw[i] = W;
+        if (rh[i] > H) rh[i] = H;
+        needW = rw[i] + kApron; needH = rh[i] + kApron;
+    }
+}
+
 }  // namespace
 
 void FreePostprocess(void** scratch) {
     if (!scratch || !*scratch) return;
     PostScratch* s = static_cast<PostScratch*>(*scratch);
-    if (s->rgb8) (void)hipFree(s->rgb8);
+    Release(s);
     delete s;
     *scratch = nullptr;
 }
 
 int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint32_t height, int bloomOn, void** scratch,
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err) {
-    if (bloomOn) { err = "bloom chain not built yet"; return RT_ERR_UNSUPPORTED; }
     const size_t n = (size_t)width * height;
     if (!*scratch) *scratch = new PostScratch();
     PostScratch* s = static_cast<PostScratch*>(*scratch);
-    if (s->n != n) {
-        if (s->rgb8) (void)hipFree(s->rgb8);
-        s->rgb8 = nullptr; s->n = 0;
-        if (hipMalloc((void**)&s->rgb8, n * 3) != hipSuccess) { err = "out of device memory"; return RT_ERR_DEVICE; }
-        s->n = n;
+    if (s->W != width || s->H != height) {
+        Release(s);
+        hipError_t e = hipMalloc((void**)&s->tmp, n * 16);
+        if (e == hipSuccess) e = hipMemsetAsync(s->tmp, 0, n * 16, st);
+        if (e == hipSuccess) e = hipMalloc((void**)&s->pre, n * 16);
+        for (int i = 0; i < kLevels && e == hipSuccess; ++i) e = hipMalloc((void**)&s->level[i], n * 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&s->rgb8, n * 3);
+        if (e != hipSuccess) { Release(s); err = hipGetErrorString(e); return RT_ERR_DEVICE; }
+        s->W = width; s->H = height;
     }
-    if (rgbaOutHost && hipMemcpyAsync(rgbaOutHost, accumLinear, n * 16, hipMemcpyDeviceToHost, st) != hipSuccess) { err = "copy failed"; return RT_ERR_DEVICE; }
+    const int W = (int)width, H = (int)height;
+    const float4* accum = static_cast<const float4*>(accumLinear);
+    const dim3 b2(32, 8);
+    auto grid2 = [&](int w, int h) { return dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)); };
+    if (bloomOn) {
+        const int ds[kLevels] = {5, 10, 20, 40};
+        int rw[kLevels], rh[kLevels];
+        Regions(W, H, rw, rh);
+        for (int i = 0; i < kLevels; ++i) {
+            const int w = W / ds[i], h = H / ds[i];
+            if (w > 0 && h > 0) hipLaunchKernelGGL(down_kernel, grid2(w, h), b2, 0, st, accum, s->tmp, W, H, w, h);
+            const int pw = min(W, rw[i] + kApron), ph = min(H, rh[i] + kApron);
+            hipLaunchKernelGGL(pre_kernel, grid2(pw, ph), b2, 0, st, s->tmp, s->pre, W, pw, ph);
+            hipLaunchKernelGGL(blur_kernel, grid2(rw[i], rh[i]), dim3(kBlurTX, kBlurTY), 0, st, s->pre, s->tmp, W, H, pw, ph, rw[i], rh[i]);
+            hipLaunchKernelGGL(up_kernel, grid2(W, H), b2, 0, st, s->tmp, s->level[i], W, H, w, h);
+        }
+    }
+    // bloom off = the raw blit of main.cpp:235-240: the accumulation is shown as it is and tmp is left alone
+    const float4* shown = accum;
+    if (bloomOn) {
+        hipLaunchKernelGGL(final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, accum, s->level[0], s->level[1], s->level[2],
+                           s->level[3], s->tmp, n);
+        shown = s->tmp;
+    }
+    if (hipGetLastError() != hipSuccess) { err = "kernel launch failed"; return RT_ERR_DEVICE; }
+    if (rgbaOutHost && hipMemcpyAsync(rgbaOutHost, shown, n * 16, hipMemcpyDeviceToHost, st) != hipSuccess) { err = "copy failed"; return RT_ERR_DEVICE; }
     if (rgb8OutHost) {
-        hipLaunchKernelGGL(to_rgb8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<const float4*>(accumLinear), s->rgb8, (uint32_t)n);
+        hipLaunchKernelGGL(to_rgb8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, shown, s->rgb8, n);
         if (hipMemcpyAsync(rgb8OutHost, s->rgb8, n * 3, hipMemcpyDeviceToHost, st) != hipSuccess) { err = "copy failed"; return RT_ERR_DEVICE; }
     }
-    if (hipStreamSynchronize(st) != hipSuccess) { err = "sync failed"; return RT_ERR_DEVICE; }
+    if (hipStreamSynchronize(st) != hipSuccess) { err = "stream synchronisation failed"; return RT_ERR_DEVICE; }
     return RT_OK;
 }
 
