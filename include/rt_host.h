@@ -54,6 +54,51 @@ const char *rth_scene_warning(const rth_scene *scene, uint32_t i);
 /* Uploads a scene and its material table to a renderer: rt_scene_upload + rt_set_materials. */
 int rth_scene_send(const rth_scene *scene, rt_context *ctx);
 
+/* ---- controls (CPU only): the reference's camera and key handling without a window ---- */
+typedef struct rth_camera rth_camera;
+rth_camera *rth_camera_create(void);                              /* defaults of Include/Camera.h:7-11 */
+void rth_camera_destroy(rth_camera *cam);
+void rth_camera_key(rth_camera *cam, int glfwKey, int action);    /* Camera::OnEvent, src/Camera.cpp:137-143 */
+int rth_camera_tick(rth_camera *cam);                             /* Camera::Tick; 1 when the camera changed */
+/* out[9] = position xyz, facing xyz, fov (rad), viewportWidth, viewportDistance */
+void rth_camera_get(const rth_camera *cam, float *out9);
+void rth_camera_set_pose(rth_camera *cam, const float *position3, const float *facing3);   /* SetPosition + SetFacing */
+/* Bounce limit a key press selects (src/BounceLimitManager.cpp:14-48), or -1 for other keys. */
+int rth_bounce_limit_from_key(int glfwKey);
+/* u_RandSeed triples of the first nFrames frames of a fresh process (src/Scene.cpp:31). */
+void rth_rand_seed_triples(uint32_t nFrames, float *out3);
+/* Object paths a RayTracer.ini names, newline separated, into buf; returns their number or -1.
+ * skyboxDir (may be NULL) receives [SkyBox] Path. */
+int rth_ini_object_paths(const char *iniPath, char *buf, uint32_t bufSize, char *skyboxDir, uint32_t skyboxDirSize);
+int rth_write_png_rgb8(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb, int flipVertically);
+
+/* ---- headless frame loop: src/main.cpp:224-279 without a window ---- */
+typedef struct rth_app rth_app;
+typedef struct rth_app_state {
+    float camera[9];             /* as rth_camera_get */
+    float last_seed[3];          /* u_RandSeed of the last tick */
+    uint32_t next_frame_index;   /* u_FrameIndex the next tick will use */
+    uint32_t bounce_limit;
+    int32_t recorder_state;      /* 0 nothing, 1 recording, 2 playback */
+    uint32_t poses_left;
+    uint32_t images_written;
+} rth_app_state;
+int rth_app_create(rt_context *ctx, uint32_t width, uint32_t height, rth_app **out);
+void rth_app_destroy(rth_app *app);
+int rth_app_load_objects(rth_app *app, const char *const *paths, uint32_t nPaths, int buildThreads);
+void rth_app_key(rth_app *app, int glfwKey, int action);          /* key_callback, src/main.cpp:289-296 */
+int rth_app_tick(rth_app *app);                                   /* one loop iteration */
+int rth_app_read_display(rth_app *app, float *rgba, uint8_t *rgb8);
+void rth_app_get_state(const rth_app *app, rth_app_state *out);
+/* bloom: run the bloom chain (the reference always does); postEveryFrame: run it on every tick as
+ * the reference does (0 = only when an image is read); framesPerImage / recordEveryFrames replace the
+ * Recorder's 5000 ms / 10 ms intervals; outputDir receives raytrace-out-<n>.png. */
+void rth_app_configure(rth_app *app, int bloom, int postEveryFrame, uint32_t framesPerImage, uint32_t recordEveryFrames,
+                       const char *outputDir, int flipVertically);
+void rth_app_push_pose(rth_app *app, const float *position3, const float *facing3);
+int rth_app_save_poses(const rth_app *app, const char *path);
+int rth_app_load_poses(rth_app *app, const char *path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,6 +137,10 @@ int rt_primary_ids(rt_context *ctx, const float *seed3, int32_t *out3);
  * Recorder::WriteTexture reads back (Include/Recorder.h:93-100). */
 int rt_postprocess(rt_context *ctx, int bloom_on, float *rgba_out, uint8_t *rgb8_out);
 
+/* Reads the image the last rt_postprocess(bloom_on = 1) left on display (the reference's tmp
+ * texture) without running the chain again. */
+int rt_display_read(rt_context *ctx, float *rgba_out, uint8_t *rgb8_out);
+
 int rt_get_counters(rt_context *ctx, rt_counters *out, int reset);
 /* full != 0: rt_render also tallies node pops, boxes, triangles and texture fetches (an
  * instrumented kernel, a few percent slower). full == 0 (default): only rays and paths. */

@@ -31,6 +31,12 @@ class rth_bvh_stats(ctypes.Structure):
                 ("degenerate_splits", ctypes.c_uint64), ("leaf_depth_sum", ctypes.c_uint64), ("build_ms", ctypes.c_double)]
 
 
+class rth_app_state(ctypes.Structure):
+    _fields_ = [("camera", ctypes.c_float * 9), ("last_seed", ctypes.c_float * 3), ("next_frame_index", ctypes.c_uint32),
+                ("bounce_limit", ctypes.c_uint32), ("recorder_state", ctypes.c_int32), ("poses_left", ctypes.c_uint32),
+                ("images_written", ctypes.c_uint32)]
+
+
 # name -> (restype, argtypes); this table is also what the symbol-export test checks against the headers
 P, I, U32, U64P, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.c_float
 SIGNATURES = {
@@ -51,6 +57,7 @@ SIGNATURES = {
     "rt_sync": (I, [P]),
     "rt_primary_ids": (I, [P, P, P]),
     "rt_postprocess": (I, [P, I, P, P]),
+    "rt_display_read": (I, [P, P, P]),
     "rt_get_counters": (I, [P, ctypes.POINTER(rt_counters), I]),
     "rt_set_counting": (I, [P, I]),
     "rt_set_shard": (I, [P, U32, U32]),
@@ -73,6 +80,27 @@ SIGNATURES = {
     "rth_scene_warning_count": (U32, [P]),
     "rth_scene_warning": (ctypes.c_char_p, [P, U32]),
     "rth_scene_send": (I, [P, P]),
+    "rth_camera_create": (P, []),
+    "rth_camera_destroy": (None, [P]),
+    "rth_camera_key": (None, [P, I, I]),
+    "rth_camera_tick": (I, [P]),
+    "rth_camera_get": (None, [P, P]),
+    "rth_camera_set_pose": (None, [P, P, P]),
+    "rth_bounce_limit_from_key": (I, [I]),
+    "rth_rand_seed_triples": (None, [U32, P]),
+    "rth_ini_object_paths": (I, [ctypes.c_char_p, ctypes.c_char_p, U32, ctypes.c_char_p, U32]),
+    "rth_write_png_rgb8": (I, [ctypes.c_char_p, U32, U32, P, I]),
+    "rth_app_create": (I, [P, U32, U32, ctypes.POINTER(P)]),
+    "rth_app_destroy": (None, [P]),
+    "rth_app_load_objects": (I, [P, ctypes.POINTER(ctypes.c_char_p), U32, I]),
+    "rth_app_key": (None, [P, I, I]),
+    "rth_app_tick": (I, [P]),
+    "rth_app_read_display": (I, [P, P, P]),
+    "rth_app_get_state": (None, [P, ctypes.POINTER(rth_app_state)]),
+    "rth_app_configure": (None, [P, I, I, U32, U32, ctypes.c_char_p, I]),
+    "rth_app_push_pose": (None, [P, P, P]),
+    "rth_app_save_poses": (I, [P, ctypes.c_char_p]),
+    "rth_app_load_poses": (I, [P, ctypes.c_char_p]),
 }
 
 _lib = None
@@ -85,6 +113,13 @@ def lib():
             raise RuntimeError(
                 "librt_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C raytracing_amd/csrc`; there is no CPU fallback")
+        # PyTorch ships its own copy of the HIP/HSA runtime under the same SONAMEs as the system one this
+        # library links to. Whichever is loaded first serves the whole process; loading torch's first
+        # keeps torch (device memory, streams, torch.distributed) and this library on one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

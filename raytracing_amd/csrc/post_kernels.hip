@@ -187,6 +187,19 @@ void FreePostprocess(void** scratch) {
     *scratch = nullptr;
 }
 
+int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err) {
+    PostScratch* s = scratch ? static_cast<PostScratch*>(*scratch) : nullptr;
+    if (!s || s->W != width || s->H != height) { err = "nothing on display yet (run rt_postprocess with bloom_on = 1 first)"; return RT_ERR_STATE; }
+    const size_t n = (size_t)width * height;
+    if (rgbaOutHost && hipMemcpyAsync(rgbaOutHost, s->tmp, n * 16, hipMemcpyDeviceToHost, st) != hipSuccess) { err = "copy failed"; return RT_ERR_DEVICE; }
+    if (rgb8OutHost) {
+        hipLaunchKernelGGL(to_rgb8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->tmp, s->rgb8, n);
+        if (hipMemcpyAsync(rgb8OutHost, s->rgb8, n * 3, hipMemcpyDeviceToHost, st) != hipSuccess) { err = "copy failed"; return RT_ERR_DEVICE; }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { err = "stream synchronisation failed"; return RT_ERR_DEVICE; }
+    return RT_OK;
+}
+
 int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint32_t height, int bloomOn, void** scratch,
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err) {
     const size_t n = (size_t)width * height;

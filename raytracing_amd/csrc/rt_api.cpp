@@ -24,6 +24,7 @@ void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t widt
                   uint32_t shardTiles, bool toTiled);
 int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint32_t height, int bloomOn, void** scratch,
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
+int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 void FreePostprocess(void** scratch);
 }  // namespace rtd
 
@@ -467,6 +468,15 @@ int rt_postprocess(rt_context* c, int bloom_on, float* rgba_out, uint8_t* rgb8_o
     std::string err;
     int rc = RunPostprocess(c->stream, c->dLinear, c->width, c->height, bloom_on, &c->postScratch, rgba_out, rgb8_out, err);
     if (rc != RT_OK) return Fail(c, rc, "rt_postprocess: %s", err.c_str());
+    return RT_OK;
+}
+
+int rt_display_read(rt_context* c, float* rgba_out, uint8_t* rgb8_out) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::string err;
+    int rc = ReadDisplay(c->stream, &c->postScratch, c->width, c->height, rgba_out, rgb8_out, err);
+    if (rc != RT_OK) return Fail(c, rc, "rt_display_read: %s", err.c_str());
     return RT_OK;
 }
 

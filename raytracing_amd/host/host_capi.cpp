@@ -93,3 +93,92 @@ int rth_scene_send(const rth_scene* s, rt_context* ctx) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// controls and headless frame loop
+// ---------------------------------------------------------------------------------------------
+#include <cstring>
+
+#include "app.h"
+#include "controls.h"
+
+struct rth_camera { rta::Camera cam; };
+struct rth_app { rta::HeadlessApp app; rth_app(rt_context* c, uint32_t w, uint32_t h) : app(c, w, h) {} };
+
+namespace {
+void FillCamera(const rta::Camera& c, float* o) {
+    o[0] = c.Position().x; o[1] = c.Position().y; o[2] = c.Position().z;
+    o[3] = c.Facing().x; o[4] = c.Facing().y; o[5] = c.Facing().z;
+    o[6] = c.Fov(); o[7] = c.ViewportWidth(); o[8] = c.ViewportDistance();
+}
+}  // namespace
+
+extern "C" {
+
+rth_camera* rth_camera_create(void) { return new rth_camera(); }
+void rth_camera_destroy(rth_camera* c) { delete c; }
+void rth_camera_key(rth_camera* c, int key, int action) { c->cam.OnEvent(rta::KeyEvent{key, action}); }
+int rth_camera_tick(rth_camera* c) { return c->cam.Tick() ? 1 : 0; }
+void rth_camera_get(const rth_camera* c, float* out9) { FillCamera(c->cam, out9); }
+void rth_camera_set_pose(rth_camera* c, const float* p, const float* f) {
+    c->cam.SetPosition({p[0], p[1], p[2]});
+    c->cam.SetFacing({f[0], f[1], f[2]});
+}
+int rth_bounce_limit_from_key(int key) { auto b = rta::BounceLimitFromKey(key); return b ? (int)*b : -1; }
+void rth_rand_seed_triples(uint32_t n, float* out3) { rta::GlibcRand r; for (uint32_t i = 0; i < n; ++i) r.NextSeedTriple(out3 + 3 * (size_t)i); }
+
+int rth_ini_object_paths(const char* iniPath, char* buf, uint32_t bufSize, char* skyboxDir, uint32_t skyboxDirSize) {
+    try {
+        std::string sky;
+        std::vector<std::string> paths = rta::HeadlessApp::ObjectPathsFromIni(iniPath, &sky);
+        std::string joined;
+        for (size_t i = 0; i < paths.size(); ++i) { if (i) joined += "\n"; joined += paths[i]; }
+        if (buf && bufSize) { std::strncpy(buf, joined.c_str(), bufSize - 1); buf[bufSize - 1] = 0; }
+        if (skyboxDir && skyboxDirSize) { std::strncpy(skyboxDir, sky.c_str(), skyboxDirSize - 1); skyboxDir[skyboxDirSize - 1] = 0; }
+        return (int)paths.size();
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+int rth_write_png_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* rgb, int flip) {
+    return rta::WritePngRgb8(path, w, h, rgb, flip != 0) ? RT_OK : RT_ERR_INVALID;
+}
+
+int rth_app_create(rt_context* ctx, uint32_t w, uint32_t h, rth_app** out) {
+    if (!ctx || !out) return RT_ERR_INVALID;
+    *out = new rth_app(ctx, w, h);
+    return RT_OK;
+}
+void rth_app_destroy(rth_app* a) { delete a; }
+int rth_app_load_objects(rth_app* a, const char* const* paths, uint32_t n, int threads) {
+    std::vector<std::string> p;
+    for (uint32_t i = 0; i < n; ++i) p.emplace_back(paths[i]);
+    return a->app.LoadObjects(p, threads);
+}
+void rth_app_key(rth_app* a, int key, int action) { a->app.OnKey(key, action); }
+int rth_app_tick(rth_app* a) { return a->app.Tick(); }
+int rth_app_read_display(rth_app* a, float* rgba, uint8_t* rgb8) { return a->app.ReadDisplay(rgba, rgb8); }
+void rth_app_get_state(const rth_app* a, rth_app_state* o) {
+    rta::HeadlessApp& app = const_cast<rth_app*>(a)->app;
+    FillCamera(app.GetCamera(), o->camera);
+    for (int k = 0; k < 3; ++k) o->last_seed[k] = app.LastSeed()[k];
+    o->next_frame_index = app.FrameIndex(); o->bounce_limit = app.BounceLimit();
+    o->recorder_state = (int32_t)app.GetRecorder().GetState();
+    o->poses_left = (uint32_t)app.GetRecorder().PosesLeft(); o->images_written = app.GetRecorder().ImagesWritten();
+}
+void rth_app_configure(rth_app* a, int bloom, int postEveryFrame, uint32_t framesPerImage, uint32_t recordEveryFrames, const char* outputDir,
+                       int flip) {
+    a->app.bloom = bloom != 0; a->app.postprocessEveryFrame = postEveryFrame != 0;
+    rta::Recorder& r = a->app.GetRecorder();
+    if (framesPerImage) r.framesPerImage = framesPerImage;
+    if (recordEveryFrames) r.recordEveryFrames = recordEveryFrames;
+    if (outputDir) r.outputDir = outputDir;
+    r.flipVertically = flip != 0;
+}
+void rth_app_push_pose(rth_app* a, const float* p, const float* f) {
+    a->app.GetRecorder().PushPose(rta::Pose{{p[0], p[1], p[2]}, {f[0], f[1], f[2]}});
+}
+int rth_app_save_poses(const rth_app* a, const char* path) { return const_cast<rth_app*>(a)->app.GetRecorder().SavePoses(path) ? RT_OK : RT_ERR_INVALID; }
+int rth_app_load_poses(rth_app* a, const char* path) { return a->app.GetRecorder().LoadPoses(path) ? RT_OK : RT_ERR_INVALID; }
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+"""Multi-GPU plumbing.
+
+CPU: world_size-2 gloo run of the tile-mode exchange (shard -> gather -> assemble) and of the
+frame-mode pose assignment, with the CPU oracle standing in for the renderer.
+GPU (one device): two sharded contexts render the two halves; assembled image == unsharded image, bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from raytracing_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("size,world", [((64, 40), 2), ((100, 52), 3), ((96, 54), 8), ((8, 8), 4)])
+def test_extract_assemble_roundtrip(size, world):
+    W, H = size
+    img = np.random.default_rng(1).random((H, W, 4), dtype=np.float32)
+    flat = np.concatenate([sharding.extract_shard_numpy(img, r, world) for r in range(world)])
+    assert flat.size == world * sharding.shard_floats(W, H, world)
+    assert (sharding.assemble_numpy(flat, W, H, world) == img).all()
+
+
+def test_pose_assignment_covers_every_pose_once():
+    for n, world in ((600, 8), (7, 2), (3, 8)):
+        seen = sorted(p for r in range(world) for p in sharding.poses_of_rank(n, r, world))
+        assert seen == list(range(n))
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/oracle"); sys.path.insert(0, ROOT + "/tests")
+from raytracing_amd import scenes, sharding
+from rt_oracle import Oracle
+from util import make_scene, setup
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H = 72, 40
+sc = make_scene("lightbox")
+noise, sky, seeds = scenes.noise_texture(32, 24), scenes.sky_cubemap(16), scenes.frame_seeds(2)
+o = Oracle(W, H, threads=2)
+setup(o, sc, noise, sky, bounce_limit=4)
+o.render(0, seeds)
+full = o.read_accum()
+# a rank only contributes its own tiles: everything else in its local image is poisoned
+shard = torch.from_numpy(sharding.extract_shard_numpy(full, rank, world))
+gathered = [torch.empty_like(shard) for _ in range(world)] if rank == 0 else None
+dist.gather(shard, gathered, dst=0)
+if rank == 0:
+    img = sharding.assemble_numpy(torch.cat(gathered).numpy(), W, H, world)
+    assert (img.view(np.uint32) == full.view(np.uint32)).all(), "assembled image differs"
+# frame mode: poses dealt round-robin, 8-bit frames gathered to rank 0
+mine = sharding.poses_of_rank(5, rank, world)
+frames = torch.zeros((3, 4), dtype=torch.uint8)
+for j, p in enumerate(mine):
+    frames[j] = p + 1
+out = [torch.empty_like(frames) for _ in range(world)] if rank == 0 else None
+dist.gather(frames, out, dst=0)
+if rank == 0:
+    got = sorted(int(v) for t in out for v in t[:, 0] if v)
+    assert got == [1, 2, 3, 4, 5], got
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_gloo_world2_tile_gather_and_frame_mode(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text("ROOT = %r\n" % ROOT + WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_gpu_sharded_render_equals_unsharded(world):
+    import ctypes
+    import torch
+    import raytracing_amd as ra
+    from raytracing_amd import scenes
+    from util import differing_pixels, make_scene, setup
+    W, H = 104, 56
+    sc = make_scene("lightbox")
+    noise, sky, seeds = scenes.noise_texture(64, 48), scenes.sky_cubemap(32), scenes.frame_seeds(3)
+    whole = ra.Renderer(W, H)
+    setup(whole, sc, noise, sky, bounce_limit=4)
+    whole.render(0, seeds)
+    want = whole.read_accum()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    per = sharding.shard_floats(W, H, world)
+    flat = torch.zeros(world * per, dtype=torch.float32, device="cuda")
+    total_rays = 0
+    for rank in range(world):
+        r = ra.Renderer(W, H)
+        setup(r, sc, noise, sky, bounce_limit=4)
+        r.set_shard(rank, world)
+        assert r.shard_tiles() * 64 * 4 == per
+        r.render(0, seeds)
+        r.sync()
+        total_rays += r.counters()["rays"]
+        assert hip.hipMemcpy(flat.data_ptr() + rank * per * 4, r.shard_device_ptr(), per * 4, 3) == 0   # device to device
+        with pytest.raises(ra.RtError):
+            r.read_accum()               # a shard alone is not an image
+        r.close()
+    torch.cuda.synchronize()
+    root = ra.Renderer(W, H)
+    root.assemble(flat.data_ptr(), world)
+    got = root.read_accum()
+    assert differing_pixels(got, want) == 0
+    assert (sharding.assemble_numpy(flat.cpu().numpy(), W, H, world) == want).all()
+    assert total_rays == whole.counters()["rays"]
+    root.close()
+    whole.close()
