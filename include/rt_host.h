@@ -71,6 +71,9 @@ void rth_rand_seed_triples(uint32_t nFrames, float *out3);
  * skyboxDir (may be NULL) receives [SkyBox] Path. */
 int rth_ini_object_paths(const char *iniPath, char *buf, uint32_t bufSize, char *skyboxDir, uint32_t skyboxDirSize);
 int rth_write_png_rgb8(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb, int flipVertically);
+/* PNG decode as the reference's stbi_load(path, .., channels) (src/main.cpp:64,96): 8-bit pixels, rows in file
+ * order, converted to 3 or 4 channels. Call with pixels == NULL to get the size. Returns 0 or RT_ERR_INVALID. */
+int rth_read_png(const char *path, int channels, uint32_t *width, uint32_t *height, uint8_t *pixels, uint64_t capacity);
 
 /* ---- headless frame loop: src/main.cpp:224-279 without a window ---- */
 typedef struct rth_app rth_app;

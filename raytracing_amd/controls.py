@@ -66,6 +66,23 @@ def write_png(path, rgb, flip=False):
         raise IOError("cannot write " + path)
 
 
+def read_png(path, channels=3):
+    """Decodes a PNG like the reference's stbi_load(path, ..., channels): (H, W, channels) uint8, file row order."""
+    L = _lib.lib()
+    w, h = ctypes.c_uint32(), ctypes.c_uint32()
+    if L.rth_read_png(path.encode(), channels, ctypes.byref(w), ctypes.byref(h), None, 0) != 0:
+        raise IOError("cannot decode " + path)
+    out = np.empty((h.value, w.value, channels), dtype=np.uint8)
+    if L.rth_read_png(path.encode(), channels, None, None, out.ctypes.data, out.nbytes) != 0:
+        raise IOError("cannot decode " + path)
+    return out
+
+
+def load_skybox(directory):
+    """The six faces of a sky-box directory in the reference's order (src/main.cpp:52-59)."""
+    return np.stack([read_png("%s/%s.png" % (directory, n), 4) for n in ("right", "left", "top", "bottom", "front", "back")])
+
+
 class HeadlessApp:
     """The reference's frame loop without a window, driving a Renderer."""
 

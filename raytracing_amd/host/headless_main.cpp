@@ -1,0 +1,115 @@
+// raytracer_headless — the reference's executable without a window (src/main.cpp:337-367):
+// reads RayTracer.ini, loads the sky box, the noise texture and the objects, then runs the frame
+// loop for a number of frames (optionally replaying key events or a pose file) and writes PNGs.
+//
+//   raytracer_headless [--ini RayTracer.ini] [--noise ./Textures/Noise/rgbNoise.png]
+//                      [--width 1280 --height 720] [--frames 64] [--device 0] [--threads 8]
+//                      [--keys "K4 W+ 10 W- 50"] [--poses file --spp 256] [--out shots] [--no-bloom] [--flip]
+// --keys: tokens separated by blanks: NAME = tap, NAME+ = press, NAME- = release, a number = that many frames.
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "app.h"
+#include "image_io.h"
+#include "rt_mi355x.h"
+
+using namespace rta;
+
+static int Die(const char* what, rt_context* ctx = nullptr) {
+    std::fprintf(stderr, "error: %s%s%s\n", what, ctx ? ": " : "", ctx ? rt_last_error(ctx) : "");
+    return 1;
+}
+
+int main(int argc, char** argv) {
+    std::string ini = "RayTracer.ini", noisePath = "./Textures/Noise/rgbNoise.png", keys, poses, outDir = "shots";
+    uint32_t width = 1280, height = 720, frames = 64, spp = 256;   // window size of src/main.cpp:28-29
+    int device = 0, threads = 8;
+    bool bloom = true, flip = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "--ini") ini = next(); else if (a == "--noise") noisePath = next(); else if (a == "--width") width = std::atoi(next());
+        else if (a == "--height") height = std::atoi(next()); else if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--device") device = std::atoi(next()); else if (a == "--threads") threads = std::atoi(next());
+        else if (a == "--keys") keys = next(); else if (a == "--poses") poses = next(); else if (a == "--spp") spp = std::atoi(next());
+        else if (a == "--out") outDir = next(); else if (a == "--no-bloom") bloom = false; else if (a == "--flip") flip = true;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    std::string skyDir;
+    std::vector<std::string> objects;
+    try { objects = HeadlessApp::ObjectPathsFromIni(ini, &skyDir); }
+    catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 1; }
+
+    rt_context* ctx = nullptr;
+    if (rt_create(device, width, height, &ctx) != RT_OK) { std::fprintf(stderr, "error: %s\n", rt_last_global_error()); return 1; }
+
+    // sky box: right, left, top, bottom, front, back -> +X,-X,+Y,-Y,+Z,-Z (src/main.cpp:52-70)
+    static const char* kFaces[6] = {"right.png", "left.png", "top.png", "bottom.png", "front.png", "back.png"};
+    std::vector<Image8> faces(6);
+    const uint8_t* facePtr[6];
+    for (int f = 0; f < 6; ++f) {
+        std::string err, p = skyDir + "/" + kFaces[f];
+        if (!LoadPng(p, 4, faces[f], &err)) { std::fprintf(stderr, "Failed to load texture at path: %s (%s)\n", p.c_str(), err.c_str()); return 1; }
+        if (faces[f].width != faces[f].height || faces[f].width != faces[0].width) return Die("sky box faces must be square and of one size");
+        facePtr[f] = faces[f].pixels.data();
+    }
+    if (rt_set_skybox(ctx, facePtr, faces[0].width) != RT_OK) return Die("rt_set_skybox", ctx);
+    Image8 noise;
+    std::string err;
+    if (!LoadPng(noisePath, 3, noise, &err)) { std::fprintf(stderr, "Failed to load noise texture at path: %s (%s)\n", noisePath.c_str(), err.c_str()); return 1; }
+    if (rt_set_noise(ctx, noise.pixels.data(), noise.width, noise.height) != RT_OK) return Die("rt_set_noise", ctx);
+
+    HeadlessApp app(ctx, width, height);
+    app.bloom = bloom;
+    if (app.LoadObjects(objects, threads) != RT_OK) return Die("loading objects", ctx);
+    for (const std::string& w : app.Scene().warnings) std::printf("%s\n", w.c_str());
+    const BvhStats& st = app.Scene().stats;
+    std::printf("triangles count: %u\nnumber of bounding boxes: %u\nnumber of total splits: %llu\nnumber of leaf nodes: %u\n"
+                "constructing BVH structure took: %.0fms\n", app.Scene().TriangleCount(), app.Scene().NodeCount() + 1,
+                (unsigned long long)st.splits, st.leaves, st.buildMs);
+
+    Recorder& rec = app.GetRecorder();
+    rec.outputDir = outDir; rec.flipVertically = flip; rec.framesPerImage = spp;
+    static const std::map<std::string, int> kNames = {
+        {"W", kKeyW}, {"A", kKeyA}, {"S", kKeyS}, {"D", kKeyD}, {"C", kKeyC}, {"R", kKeyR}, {"P", kKeyP}, {"B", kKeyB}, {"SPACE", kKeySpace},
+        {"CTRL", kKeyLeftControl}, {"LSHIFT", kKeyLeftShift}, {"RSHIFT", kKeyRightShift}, {"UP", kKeyUp}, {"DOWN", kKeyDown},
+        {"LEFT", kKeyLeft}, {"RIGHT", kKeyRight}, {"GRAVE", kKeyGrave}, {"K1", kKey1}, {"K2", kKey2}, {"K3", kKey3}, {"K4", kKey4},
+        {"K5", kKey5}, {"K6", kKey6}};
+    auto run = [&](uint32_t n) { for (uint32_t k = 0; k < n; ++k) if (app.Tick() != RT_OK) return false; return true; };
+    if (!poses.empty()) {
+        if (!rec.LoadPoses(poses)) return Die("cannot read the pose file");
+        const uint32_t total = (uint32_t)rec.PosesLeft();
+        app.OnKey(kKeyP, kPress); app.OnKey(kKeyP, kRelease);
+        if (!run((total + 1) * spp + 1)) return Die("rendering", ctx);
+        std::printf("wrote %u images to %s\n", rec.ImagesWritten(), outDir.c_str());
+    } else {
+        std::istringstream ks(keys);
+        std::string tok;
+        uint32_t done = 0;
+        while (ks >> tok) {
+            if (std::isdigit((unsigned char)tok[0])) { uint32_t n = std::atoi(tok.c_str()); if (!run(n)) return Die("rendering", ctx); done += n; continue; }
+            char mode = tok.back();
+            std::string name = (mode == '+' || mode == '-') ? tok.substr(0, tok.size() - 1) : tok;
+            auto it = kNames.find(name);
+            if (it == kNames.end()) { std::fprintf(stderr, "unknown key %s\n", name.c_str()); return 2; }
+            if (mode != '-') app.OnKey(it->second, kPress);
+            if (mode != '+') app.OnKey(it->second, kRelease);
+        }
+        if (done < frames && !run(frames - done)) return Die("rendering", ctx);
+        std::vector<uint8_t> rgb8((size_t)width * height * 3);
+        if (app.ReadDisplay(nullptr, rgb8.data()) != RT_OK) return Die("reading the image", ctx);
+        std::string out = outDir + ".png";
+        if (!WritePngRgb8(out, width, height, rgb8.data(), flip)) return Die("cannot write the image");
+        rt_counters c;
+        rt_get_counters(ctx, &c, 0);
+        std::printf("wrote %s after %u frames (%llu rays)\n", out.c_str(), app.FrameIndex(), (unsigned long long)c.rays);
+    }
+    rt_destroy(ctx);
+    return 0;
+}

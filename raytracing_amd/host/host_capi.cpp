@@ -101,6 +101,7 @@ int rth_scene_send(const rth_scene* s, rt_context* ctx) {
 
 #include "app.h"
 #include "controls.h"
+#include "image_io.h"
 
 struct rth_camera { rta::Camera cam; };
 struct rth_app { rta::HeadlessApp app; rth_app(rt_context* c, uint32_t w, uint32_t h) : app(c, w, h) {} };
@@ -142,6 +143,18 @@ int rth_ini_object_paths(const char* iniPath, char* buf, uint32_t bufSize, char*
 }
 int rth_write_png_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* rgb, int flip) {
     return rta::WritePngRgb8(path, w, h, rgb, flip != 0) ? RT_OK : RT_ERR_INVALID;
+}
+
+int rth_read_png(const char* path, int channels, uint32_t* width, uint32_t* height, uint8_t* pixels, uint64_t capacity) {
+    rta::Image8 img;
+    if (!path || !rta::LoadPng(path, channels, img)) return RT_ERR_INVALID;
+    if (width) *width = img.width;
+    if (height) *height = img.height;
+    if (pixels) {
+        if (capacity < img.pixels.size()) return RT_ERR_INVALID;
+        std::memcpy(pixels, img.pixels.data(), img.pixels.size());
+    }
+    return RT_OK;
 }
 
 int rth_app_create(rt_context* ctx, uint32_t w, uint32_t h, rth_app** out) {

@@ -93,3 +93,31 @@ def test_recorder_playback_writes_one_image_per_pose(objects, tmp_path):
     app.close(); r.close()
     # the recorder samples the camera before the frame's movement is applied (main.cpp:228 precedes :230)
     assert abs(last[0] - 0.4) < 1e-6
+
+
+def test_headless_executable_matches_python_driver(objects, tmp_path):
+    """The C++ executable (ini -> PNG textures -> objects -> frames -> PNG) against the same steps driven from Python."""
+    import subprocess
+    from PIL import Image
+    root = tmp_path / "install"
+    (root / "Textures" / "Sky").mkdir(parents=True)
+    (root / "Textures" / "Noise").mkdir(parents=True)
+    for f, name in enumerate(("right", "left", "top", "bottom", "front", "back")):
+        Image.fromarray(SKY[f], "RGBA").save(str(root / "Textures" / "Sky" / (name + ".png")))
+    Image.fromarray(NOISE, "RGB").save(str(root / "Textures" / "Noise" / "rgbNoise.png"))
+    obj_dir = os.path.dirname(objects[0])
+    scenes.write_ini(str(root / "RayTracer.ini"), obj_dir, [os.path.basename(p) for p in objects], skybox_path=str(root / "Textures" / "Sky"))
+    exe = os.path.join(os.path.dirname(ra.__file__), "raytracer_headless")
+    out = str(tmp_path / "frame")
+    r = subprocess.run([exe, "--ini", str(root / "RayTracer.ini"), "--noise", str(root / "Textures" / "Noise" / "rgbNoise.png"),
+                        "--width", str(W), "--height", str(H), "--keys", "K3 W+ 2 W- 4", "--frames", "6", "--out", out],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "triangles count: 1366" in r.stdout
+    got = np.asarray(Image.open(out + ".png"))
+    rr, app = make_app(objects)
+    app.tap(KEY["K3"])
+    app.key(KEY["W"], PRESS); app.tick(2); app.key(KEY["W"], RELEASE); app.tick(4)
+    _, want = app.read_display()
+    assert (got == want).all()
+    app.close(); rr.close()

@@ -123,3 +123,31 @@ def test_png_writer_roundtrip(tmp_path):
     big = np.random.default_rng(1).integers(0, 256, size=(200, 300, 3), dtype=np.uint8)   # several deflate blocks
     controls.write_png(p, big)
     assert (np.asarray(Image.open(p)) == big).all()
+
+
+def test_png_reader_matches_pil(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for mode, shape in (("RGB", (19, 31, 3)), ("RGBA", (16, 16, 4)), ("L", (9, 40))):
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        p = str(tmp_path / (mode + ".png"))
+        Image.fromarray(a, mode).save(p)
+        for ch in (3, 4):
+            want = np.asarray(Image.open(p).convert("RGB" if ch == 3 else "RGBA"))
+            assert (controls.read_png(p, ch) == want).all(), (mode, ch)
+    pal = Image.fromarray(rng.integers(0, 256, size=(12, 12, 3), dtype=np.uint8), "RGB").quantize(16)
+    p = str(tmp_path / "pal.png")
+    pal.save(p)
+    assert (controls.read_png(p, 3) == np.asarray(Image.open(p).convert("RGB"))).all()
+    with pytest.raises(IOError):
+        controls.read_png(str(tmp_path / "missing.png"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Textures"), reason="the reference's textures only exist in the build container")
+def test_png_reader_on_reference_textures():
+    from PIL import Image
+    for rel, ch in (("Noise/rgbNoise.png", 3), ("Noise/rgbSmall.png", 3), ("DaylightBox/top.png", 4), ("BlackStudio/left.png", 4)):
+        p = "/root/reference/Textures/" + rel
+        want = np.asarray(Image.open(p).convert("RGB" if ch == 3 else "RGBA"))
+        assert (controls.read_png(p, ch) == want).all(), rel
+    assert controls.load_skybox("/root/reference/Textures/DaylightBox").shape == (6, 511, 511, 4)
