@@ -123,44 +123,71 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # RT_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share devices and
+    # the gather goes through host memory. The real thing is nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     K, Wm = args.steps, args.warmup
     sc, W, H, bl = load_workload(args.workload, threads=min(16, os.cpu_count() or 1))
     noise, sky = scenes.noise_texture(), scenes.sky_cubemap()
     seeds = scenes.frame_seeds(Wm + K)
 
-    r = ra.Renderer(W, H, device=local_rank)
+    r = ra.Renderer(W, H, device=device)
     setup(r, sc, noise, sky, bl)
     root = None
-    shard = gathered = None
+    stage = flats = gathered = None
+    pending = [None, None]
     if world > 1:
         r.set_shard(rank, world)
-        per = r.shard_tiles()
-        # torch tensors are only plumbing: device memory for the gather's send/receive sides
-        shard = torch.empty(per * 64 * 4, dtype=torch.float32, device="cuda")
+        n = r.shard_tiles() * 64 * 4
+        # torch tensors are only plumbing: device memory for the gather's send and receive sides.
+        # Two of each, so that the gather of frame k runs while frame k+1 is being traced.
+        stage = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(2)]
         if rank == 0:
-            flat = torch.empty(world * shard.numel(), dtype=torch.float32, device="cuda")
-            gathered = list(flat.chunk(world))              # the gather writes the shards back to back
-            root = ra.Renderer(W, H, device=local_rank)     # unsharded context that assembles the image
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpyDtoDAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+            flats = [torch.empty(world * n, dtype=torch.float32, device="cuda") for _ in range(2)]
+            gathered = [list(f.chunk(world)) for f in flats]     # the gather writes the shards back to back
+            root = ra.Renderer(W, H, device=device)              # unsharded context that assembles the image
+
+    def finish(k):
+        """Completes the exchange of frame k: waits for its gather, rank 0 scatters the shards into the image."""
+        b = k & 1
+        if pending[b] is None:
+            return
+        if backend == "nccl":
+            pending[b].wait()
+        if rank == 0:
+            torch.cuda.synchronize()
+            root.assemble(flats[b].data_ptr(), world)
+        pending[b] = None
 
     def step(k):
         r.render(k, seeds[k:k + 1])
-        if world > 1:
-            r.sync()
-            # shard -> send buffer (device-to-device), gather to rank 0 over RCCL/xGMI
-            hip.hipMemcpyDtoDAsync(shard.data_ptr(), r.shard_device_ptr(), shard.numel() * 4, None)
-            dist.gather(shard, gathered if rank == 0 else None, dst=0)
+        if world == 1:
+            return
+        b = k & 1
+        r.export_shard(stage[b].data_ptr())      # queued behind the frame on the renderer's stream
+        finish(k - 1)                            # the previous frame's exchange overlapped with this frame's tracing
+        r.sync()
+        if backend == "nccl":
+            pending[b] = dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+        else:
+            host = stage[b].cpu()
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
             if rank == 0:
-                torch.cuda.synchronize()
-                root.assemble(flat.data_ptr(), world)
+                flats[b].copy_(torch.cat(parts))
+            pending[b] = True
 
     def fence():
+        finish(0)
+        finish(1)
         r.sync()
         if root is not None:
             root.sync()
@@ -183,7 +210,7 @@ def main():
 
     c = r.counters(reset=True)
     kms, launches = r.kernel_time(reset=True)
-    stats = torch.tensor([dt, float(c["rays"]), float(c["paths"]), kms], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([dt, float(c["rays"]), float(c["paths"]), kms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -155,6 +155,10 @@ int rt_set_shard(rt_context *ctx, uint32_t rank, uint32_t world);
 int rt_shard_tiles(const rt_context *ctx, uint32_t *tilesPerRank);
 /* Device pointer of this context's shard: tilesPerRank * 64 * 4 floats. */
 int rt_shard_device_ptr(rt_context *ctx, void **devicePtr);
+/* Queues a device-to-device copy of the shard into `dstDevice` (tilesPerRank * 64 * 4 floats) on the
+ * context's stream, i.e. after the frames rendered so far and before those rendered next: the
+ * send buffer of a gather that overlaps with further rendering. */
+int rt_shard_export(rt_context *ctx, void *dstDevice);
 /* On the gathering rank: `gathered` is a device buffer holding world shards back to back in
  * rank order (what a gather collective delivers). Scatters them into this context's image. */
 int rt_accum_assemble(rt_context *ctx, const void *gatheredDevice, uint32_t world);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "rt_set_shard": (I, [P, U32, U32]),
     "rt_shard_tiles": (I, [P, ctypes.POINTER(U32)]),
     "rt_shard_device_ptr": (I, [P, ctypes.POINTER(P)]),
+    "rt_shard_export": (I, [P, P]),
     "rt_accum_assemble": (I, [P, P, U32]),
     "rt_set_stream": (I, [P, P]),
     "rt_kernel_time": (I, [P, ctypes.POINTER(ctypes.c_double), U64P, I]),

@@ -517,6 +517,13 @@ int rt_shard_device_ptr(rt_context* c, void** p) {
     return RT_OK;
 }
 
+int rt_shard_export(rt_context* c, void* dstDevice) {
+    if (!c || !dstDevice) return c ? Fail(c, RT_ERR_INVALID, "rt_shard_export: NULL destination") : RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(dstDevice, c->dAccum, (size_t)c->sp.shardTiles * 64 * 16, hipMemcpyDeviceToDevice, c->stream));
+    return RT_OK;
+}
+
 int rt_accum_assemble(rt_context* c, const void* gatheredDevice, uint32_t world) {
     if (!c || !gatheredDevice || world == 0) return c ? Fail(c, RT_ERR_INVALID, "rt_accum_assemble: bad argument") : RT_ERR_INVALID;
     if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_accum_assemble: the assembling context must be unsharded");

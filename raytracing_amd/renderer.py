@@ -215,6 +215,9 @@ class Renderer:
         self._ck(self.L.rt_shard_device_ptr(self.h, ctypes.byref(p)), "rt_shard_device_ptr")
         return p.value
 
+    def export_shard(self, dst_device_ptr):
+        self._ck(self.L.rt_shard_export(self.h, ctypes.c_void_p(dst_device_ptr)), "rt_shard_export")
+
     def assemble(self, gathered_device_ptr, world):
         self._ck(self.L.rt_accum_assemble(self.h, ctypes.c_void_p(gathered_device_ptr), world), "rt_accum_assemble")
 
