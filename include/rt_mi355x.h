@@ -140,6 +140,9 @@ int rt_postprocess(rt_context *ctx, int bloom_on, float *rgba_out, uint8_t *rgb8
 /* Reads the image the last rt_postprocess(bloom_on = 1) left on display (the reference's tmp
  * texture) without running the chain again. */
 int rt_display_read(rt_context *ctx, float *rgba_out, uint8_t *rgb8_out);
+/* Clears what the post-processing chain carries over from earlier frames (the reference's tmp texture),
+ * as in a freshly started process. */
+int rt_display_reset(rt_context *ctx);
 
 int rt_get_counters(rt_context *ctx, rt_counters *out, int reset);
 /* full != 0: rt_render also tallies node pops, boxes, triangles and texture fetches (an

@@ -480,6 +480,14 @@ int rt_display_read(rt_context* c, float* rgba_out, uint8_t* rgb8_out) {
     return RT_OK;
 }
 
+int rt_display_reset(rt_context* c) {
+    if (!c) return RT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    FreePostprocess(&c->postScratch);      // the next rt_postprocess starts from a zeroed tmp image
+    return RT_OK;
+}
+
 int rt_get_counters(rt_context* c, rt_counters* out, int reset) {
     if (!c || !out) return c ? Fail(c, RT_ERR_INVALID, "rt_get_counters: NULL out") : RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));

@@ -187,6 +187,9 @@ class Renderer:
         self._ck(self.L.rt_postprocess(self.h, int(bloom_on), rgba.ctypes.data, rgb8.ctypes.data if want_rgb8 else None), "rt_postprocess")
         return rgba, rgb8
 
+    def display_reset(self):
+        self._ck(self.L.rt_display_reset(self.h), "rt_display_reset")
+
     def counters(self, reset=False):
         c = rt_counters()
         self._ck(self.L.rt_get_counters(self.h, ctypes.byref(c), int(reset)), "rt_get_counters")
