@@ -249,7 +249,9 @@ def main():
                     "boxes_per_ray": round(ci["boxes_tested"] / ci["rays"], 2),
                     "tris_per_ray": round(ci["tris_tested"] / ci["rays"], 2),
                     "lane_use_new_interior_leaf_shade": [round(l / (64.0 * max(1, n)), 3) for l, n in zip(ci["sched_lanes"], ci["sched_rounds"])],
-                    "rounds_new_interior_leaf_shade": [n // launches for n in ci["sched_rounds"]]}
+                    "rounds_new_interior_leaf_shade": [n // launches for n in ci["sched_rounds"]],
+                    "wave_cycles_per_round_new_interior_leaf_shade": [round(64.0 * c / max(1, n)) for c, n in zip(ci["sched_cycles"], ci["sched_rounds"])],
+                    "wave_time_share_new_interior_leaf_shade": [round(c / max(1, sum(ci["sched_cycles"])), 3) for c in ci["sched_cycles"]]}
 
     if rank == 0:
         out = {

@@ -73,6 +73,7 @@ typedef struct rt_counters {
      * rounds a wave spent in that state's code, and how many of its 64 lanes took part */
     uint64_t sched_rounds[4];
     uint64_t sched_lanes[4];
+    uint64_t sched_cycles[4];   /* shader clock cycles the waves spent in those rounds (in units of 64 cycles) */
 } rt_counters;
 
 /* Library-level message for failures that happen before a context exists (rt_create). */

@@ -23,7 +23,8 @@ class rt_camera(ctypes.Structure):
 class rt_counters(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in ("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches",
                                                "sky_fetches", "paths", "hits")] + [("sched_rounds", ctypes.c_uint64 * 4),
-                                                                                    ("sched_lanes", ctypes.c_uint64 * 4)]
+                                                                                    ("sched_lanes", ctypes.c_uint64 * 4),
+                                                                                    ("sched_cycles", ctypes.c_uint64 * 4)]
 
 
 class rth_bvh_stats(ctypes.Structure):

@@ -14,6 +14,7 @@
 #include "rt_mi355x.h"
 
 namespace rtd {
+void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames);
 void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
                  void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
                  uint32_t tilesPerGroup);
@@ -380,6 +381,7 @@ static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* 
         f.hashX = hash(0u) + hash(f.frameIndex) + hashf(Flush(Flush(s[0]) * BLf));
         f.hashY = hash(0u) + hashf(Flush(Flush(s[1]) * BLf));
         f.weight = 1.0f / (float)(f.frameIndex + 1u);     // Fragment.glsl:487
+        f.jitterX = f.jitterY = 0.0f;                     // filled in on the device below
     }
     if (n > c->framesCap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -391,6 +393,8 @@ static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* 
     // pageable source: the copy is staged before the call returns, so `fr` may go out of scope
     HIP_TRY(c, hipMemcpyAsync(c->dFrames, fr.data(), sizeof(FrameParams) * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    LaunchPrepareFrames(c->stream, c->sp, c->dFrames, n);
+    HIP_TRY(c, hipGetLastError());
     return RT_OK;
 }
 
@@ -498,7 +502,7 @@ int rt_get_counters(rt_context* c, rt_counters* out, int reset) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->rays = t[kRays]; out->node_pops = t[kPops]; out->boxes_tested = t[kBoxes]; out->tris_tested = t[kTris];
     out->noise_fetches = t[kNoise]; out->sky_fetches = t[kSky]; out->paths = t[kPaths] + c->hostPaths; out->hits = t[kHits];
-    for (int k = 0; k < 4; ++k) { out->sched_rounds[k] = t[kRoundsNew + k]; out->sched_lanes[k] = t[kLanesNew + k]; }
+    for (int k = 0; k < 4; ++k) { out->sched_rounds[k] = t[kRoundsNew + k]; out->sched_lanes[k] = t[kLanesNew + k]; out->sched_cycles[k] = t[kCyclesNew + k]; }
     if (reset) c->hostPaths = 0;
     if (reset) HIP_TRY(c, hipMemsetAsync(c->dTotals, 0, sizeof t, c->stream));
     return RT_OK;

@@ -80,16 +80,20 @@ struct SceneParams {
 };
 
 // Per-frame uniforms, precomputed on the host where that is exact integer / single-op work.
-struct FrameParams {
-    float seedY, seedZ;          // u_RandSeed.yz (jitter lookup, Fragment.glsl:461)
+struct alignas(16) FrameParams {
     uint32_t hashX, hashY;       // frame-constant parts of the per-bounce seed, Fragment.glsl:392-393
     float weight;                // 1.0 / float(u_FrameIndex + 1), Fragment.glsl:487
     uint32_t frameIndex;
+    float jitterX, jitterY;      // texture(u_RgbNoise, u_RandSeed.yz).xy: the pixel jitter of Fragment.glsl:461,
+                                 // filled in on the device (prepare_frames_kernel) from the two seeds below
+    float seedY, seedZ;          // u_RandSeed.yz
 };
+static_assert(sizeof(FrameParams) == 32, "frame record must be 32 bytes");
 
 enum CounterSlot { kRays = 0, kPops, kBoxes, kTris, kNoise, kSky, kPaths, kHits,
                    kRoundsNew, kRoundsInterior, kRoundsLeaf, kRoundsShade,   // scheduler rounds run per state (per wave)
                    kLanesNew, kLanesInterior, kLanesLeaf, kLanesShade,       // lanes that took part in those rounds
+                   kCyclesNew, kCyclesInterior, kCyclesLeaf, kCyclesShade,   // wave time spent in those rounds, 64-cycle units
                    kCounterSlots };
 
 }  // namespace rtd

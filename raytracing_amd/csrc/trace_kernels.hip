@@ -85,17 +85,26 @@ __device__ __forceinline__ void coord_repeat(float c, int n, int& i0, int& i1, i
     i1 = (i0 == n - 1) ? 0 : i0 + 1;
 }
 
-__device__ __forceinline__ V3 sample_noise(const SceneParams& sp, float s, float t) {   // texture(u_RgbNoise, ..)
-    int x0, x1, wx, y0, y1, wy;
-    coord_repeat(s, sp.noiseW, x0, x1, wx);
-    coord_repeat(t, sp.noiseH, y0, y1, wy);
-    const uint32_t* T = sp.noise;
-    uint32_t t00 = T[y0 * sp.noiseW + x0], t10 = T[y0 * sp.noiseW + x1];
-    uint32_t t01 = T[y1 * sp.noiseW + x0], t11 = T[y1 * sp.noiseW + x1];
-    const float k = (float)(1.0 / 255.0);
-    return mk((float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 0) * k, (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 1) * k,
-              (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 2) * k);
+// A bilinear footprint: the four texels and the two 8-bit weights. Fetching and filtering are
+// separate so that a caller can request several footprints before it waits for any of them.
+struct Texels { uint32_t t00, t10, t01, t11; int wx, wy; };
+
+__device__ __forceinline__ float resolve(const Texels& q, int ch) {
+    return (float)bilerp_rgbx(q.t00, q.t10, q.t01, q.t11, q.wx, q.wy, ch) * (float)(1.0 / 255.0);
 }
+__device__ __forceinline__ V3 resolve3(const Texels& q) { return mk(resolve(q, 0), resolve(q, 1), resolve(q, 2)); }
+
+__device__ __forceinline__ Texels fetch_noise(const SceneParams& sp, float s, float t) {   // texture(u_RgbNoise, ..)
+    int x0, x1, y0, y1;
+    Texels q;
+    coord_repeat(s, sp.noiseW, x0, x1, q.wx);
+    coord_repeat(t, sp.noiseH, y0, y1, q.wy);
+    const uint32_t* T = sp.noise;
+    q.t00 = T[y0 * sp.noiseW + x0]; q.t10 = T[y0 * sp.noiseW + x1];
+    q.t01 = T[y1 * sp.noiseW + x0]; q.t11 = T[y1 * sp.noiseW + x1];
+    return q;
+}
+__device__ __forceinline__ V3 sample_noise(const SceneParams& sp, float s, float t) { return resolve3(fetch_noise(sp, s, t)); }
 
 __device__ __forceinline__ void coord_clamp(float c, int n, int& i0, int& i1, int& w) {
     float f = c * (float)n;
@@ -109,7 +118,7 @@ __device__ __forceinline__ void coord_clamp(float c, int n, int& i0, int& i1, in
 }
 
 // texture(u_Skybox, RotateAroundAxis(dir, (1,0,0), -3.1415/2)) : F:158-163,406,411
-__device__ __forceinline__ V3 sample_sky(const SceneParams& sp, V3 dir) {
+__device__ __forceinline__ Texels fetch_sky(const SceneParams& sp, V3 dir) {
     const V3 k = mk(1.0f, 0.0f, 0.0f);
     V3 d = (dir * sp.skyCos + cross3(k, dir) * sp.skySin) + (k * dot3(k, dir)) * (1.0f - sp.skyCos);
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
@@ -122,16 +131,19 @@ __device__ __forceinline__ V3 sample_sky(const SceneParams& sp, V3 dir) {
     else { sc = neg ? -d.x : d.x; tc = -d.y; }
     float ima = 0.5f / fabsf(ma);
     float s = sc * ima + 0.5f, t = tc * ima + 0.5f;
-    int x0, x1, wx, y0, y1, wy;
+    int x0, x1, y0, y1;
+    Texels q;
     const int S = sp.skySize;
-    coord_clamp(s, S, x0, x1, wx);
-    coord_clamp(t, S, y0, y1, wy);
+    coord_clamp(s, S, x0, x1, q.wx);
+    coord_clamp(t, S, y0, y1, q.wy);
     const uint32_t* T = sp.sky + (size_t)(axis * 2 + (neg ? 1 : 0)) * S * S;
-    uint32_t t00 = T[y0 * S + x0], t10 = T[y0 * S + x1], t01 = T[y1 * S + x0], t11 = T[y1 * S + x1];
-    const float kk = (float)(1.0 / 255.0);
-    return mk((float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 0) * kk, (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 1) * kk,
-              (float)bilerp_rgbx(t00, t10, t01, t11, wx, wy, 2) * kk);
+    q.t00 = T[y0 * S + x0]; q.t10 = T[y0 * S + x1]; q.t01 = T[y1 * S + x0]; q.t11 = T[y1 * S + x1];
+    return q;
 }
+
+// Moves a value that is equal in all lanes into a scalar register.
+__device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ V3 uni3(V3 v) { return mk(uni(v.x), uni(v.y), uni(v.z)); }
 
 struct Ray { V3 o, d, inv; };
 __device__ __forceinline__ Ray MakeRay(V3 o, V3 d) {            // F:135-142 (magnitude is always 1)
@@ -150,11 +162,17 @@ __device__ __forceinline__ bool hit_box(const Ray& r, float mnx, float mny, floa
 
 
 struct Tally { uint32_t rays, pops, boxes, tris, noise, sky, paths, hits; uint32_t rounds[4]; uint32_t lanes[4]; };
+// Wave time per scheduler state (counting builds only); lane 0 carries the sums.
+struct RoundClock {
+    unsigned long long t0, cycles[4];
+    __device__ __forceinline__ void start() { t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void stop(int state) { cycles[state] += __builtin_readcyclecounter() - t0; }
+};
 
 enum LaneState : int { kIdle = 0, kNewPath = 1, kInterior = 2, kLeaf = 3, kShade = 4 };
 
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 16
+#define RT_LDS_STACK 14
 #endif
 #ifndef RT_INT_STEPS
 #define RT_INT_STEPS 8
@@ -271,31 +289,62 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     }
 }
 
-// One leaf: F:285-295 with hitTriangle F:207-240; triangles in order, strictly closer wins.
+// hitTriangle, F:207-234: the distance at which L.ray meets triangle (v0, e1, e2), accepted only if
+// it passes the shader's four early returns (with its comparison operators: NaNs fall through them).
+__device__ __forceinline__ bool hit_triangle(const Ray& r, float4 a, float4 b, float4 c, float& t) {
+    V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
+    V3 h = cross3(r.d, e2);
+    float det = dot3(e1, h);
+    float invDet = 1.0f / det;
+    V3 s = r.o - v0;
+    float u = invDet * dot3(s, h);
+    V3 q = cross3(s, e1);
+    float v = invDet * dot3(r.d, q);
+    t = invDet * dot3(e2, q);
+    bool reject = (fabsf(det) < 1e-8f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < 0.0001f);
+    return !reject;
+}
+
+// One leaf: F:285-295; triangles in order, strictly closer wins. The records of the first three
+// triangles (the reference builds leaves of at most three) are requested together so that the
+// leaf costs one memory round trip; indices past the leaf's end are clamped to its last triangle
+// and their result ignored.
 template <bool COUNT>
 __device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
     const uint32_t first = L.cur & 0x07ffffffu, count = ((L.cur >> 27) & 15u) + 1u;
-    for (uint32_t i = first; i < first + count; ++i) {
+    const uint32_t last = first + count - 1u;
+    const float4* T0 = reinterpret_cast<const float4*>(sp.tris + first);
+    const float4* T1 = reinterpret_cast<const float4*>(sp.tris + min(first + 1u, last));
+    const float4* T2 = reinterpret_cast<const float4*>(sp.tris + min(first + 2u, last));
+    float4 a0 = T0[0], b0 = T0[1], c0 = T0[2];
+    float4 a1 = T1[0], b1 = T1[1], c1 = T1[2];
+    float4 a2 = T2[0], b2 = T2[1], c2 = T2[2];
+    if (COUNT) tl.tris += count;
+    float t;
+    if (hit_triangle(L.ray, a0, b0, c0, t) && L.bestT > t) { L.bestT = t; L.bestIdx = (int)first; }
+    if (hit_triangle(L.ray, a1, b1, c1, t) && count > 1u && L.bestT > t) { L.bestT = t; L.bestIdx = (int)first + 1; }
+    if (hit_triangle(L.ray, a2, b2, c2, t) && count > 2u && L.bestT > t) { L.bestT = t; L.bestIdx = (int)first + 2; }
+    for (uint32_t i = first + 3u; i <= last; ++i) {
         const float4* T = reinterpret_cast<const float4*>(sp.tris + i);
-        float4 a = T[0], b = T[1], c = T[2];
-        if (COUNT) tl.tris++;
-        V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
-        V3 h = cross3(L.ray.d, e2);
-        float det = dot3(e1, h);
-        float invDet = 1.0f / det;
-        V3 s = L.ray.o - v0;
-        float u = invDet * dot3(s, h);
-        V3 q = cross3(s, e1);
-        float v = invDet * dot3(L.ray.d, q);
-        float t = invDet * dot3(e2, q);
-        // the shader's four early returns, with its comparison operators (NaNs fall through them)
-        bool reject = (fabsf(det) < 1e-8f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < 0.0001f);
-        if (!reject && L.bestT > t) { L.bestT = t; L.bestIdx = (int)i; }
+        if (hit_triangle(L.ray, T[0], T[1], T[2], t) && L.bestT > t) { L.bestT = t; L.bestIdx = (int)i; }
     }
     pop_next<COUNT>(st, L);
 }
 
-template <bool COUNT, bool IDS>
+// Fills in the per-frame pixel jitter (F:461: the noise lookup there depends on the frame's seed
+// only, so it is done once per frame here instead of once per pixel).
+__global__ void prepare_frames_kernel(SceneParams sp, FrameParams* __restrict__ frames, uint32_t nFrames) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nFrames) return;
+    FrameParams f = frames[k];
+    V3 ro = sample_noise(sp, f.seedY + 0.007f * 0.0f, f.seedZ + 0.007f * 0.0f);
+    frames[k].jitterX = ro.x;
+    frames[k].jitterY = ro.y;
+}
+
+// COUNT: full tallies; IDS: primary-hit ids instead of radiance (one frame); SINGLE: the launch
+// renders one frame, whose parameters then live in scalar registers.
+template <bool COUNT, bool IDS, bool SINGLE>
 __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
                                                    float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
                                                    int32_t* __restrict__ ids /* IDS only: [slot][3] */,
@@ -303,20 +352,30 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                                                    uint32_t* __restrict__ queueHeads /* [8] next group per band, zeroed before the launch */,
                                                    uint32_t nGroups, uint32_t tilesPerGroup, uint32_t tallyStride) {
     __shared__ uint2 lds_stack[kLdsStack * 64];
+    __shared__ MaterialRec lds_mat[kMaxMaterials];
     const uint32_t lane = threadIdx.x;
     StackRef st;
     st.lds = lds_stack + lane;
     st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64 + lane;
 
+    // the material table is small and read at every hit: keep a copy in LDS
+    for (uint32_t j = lane; j < (uint32_t)(sizeof(MaterialRec) / 4 * kMaxMaterials); j += 64u)
+        reinterpret_cast<uint32_t*>(lds_mat)[j] = reinterpret_cast<const uint32_t*>(sp.materials)[j];
+    __syncthreads();
+
+    // Per-launch constants are the same in every lane: computed with vector instructions (there
+    // is no scalar float unit), then moved to scalar registers so they cost no vector registers.
     const uint32_t BL = sp.bounceLimit;
     const V3 camPos = mk(sp.camPos[0], sp.camPos[1], sp.camPos[2]);
     const V3 facing = mk(sp.camFacing[0], sp.camFacing[1], sp.camFacing[2]);
-    const float resx = (float)sp.width, resy = (float)sp.height;
-    const float nresx = (float)sp.noiseW, nresy = (float)sp.noiseH;
-    const float vpH = sp.vpW * (resy / resx);                                   // F:145
-    const V3 U = normalize3(cross3(facing, mk(0.0f, 0.0f, 1.0f)));              // F:147
-    const V3 Vd = normalize3(cross3(U, facing));                                // F:148
+    const float resx = uni((float)sp.width), resy = uni((float)sp.height);
+    const float nresx = uni((float)sp.noiseW), nresy = uni((float)sp.noiseH);
+    const float vpH = uni(sp.vpW * (resy / resx));                              // F:145
+    const V3 U = uni3(normalize3(cross3(facing, mk(0.0f, 0.0f, 1.0f))));        // F:147
+    const V3 Vd = uni3(normalize3(cross3(U, facing)));                          // F:148
     const uint32_t nTiles = sp.tilesX * sp.tilesY;
+    FrameParams f0 = {};
+    if (SINGLE) f0 = frames[0];
 
     // Groups of consecutive tiles are queued in 8 bands; a wave drains the band with its
     // blockIdx % 8 label first (waves with equal labels share an XCD, hence an L2), then helps
@@ -327,6 +386,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
     bool queueEmpty = false;
 
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    RoundClock rc = {0ull, {0ull, 0ull, 0ull, 0ull}};
     Lane L;
     L.state = kIdle; L.slot = 0; L.k = 0; L.bounce = 0; L.segments = 0; L.cur = kNoRef; L.top = 0;
     L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0;
@@ -335,57 +395,19 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
     V3 hitNormal = mk(0.0f, 0.0f, 0.0f);      // hitRecord.normal persists across bounces of a path (F:381)
 
     for (;;) {
-        // ---- hand waiting pixels to idle lanes ----
-        unsigned long long idleMask = __ballot(L.state == kIdle);
-        if (idleMask != 0ull) {
-            if (poolNext == poolEnd && !queueEmpty) {
-                // pull the next group of tiles: one returning atomic by lane 0, broadcast to the wave
-                for (;;) {
-                    uint32_t g = 0;
-                    if (lane == 0) g = atomicAdd(&queueHeads[band], 1u);
-                    g = __builtin_amdgcn_readfirstlane(g);
-                    const uint32_t first = band * bandSize;
-                    const uint32_t last = min(first + bandSize, nGroups);
-                    if (first + g < last) {
-                        poolNext = (first + g) * tilesPerGroup * 64u;
-                        poolEnd = min(poolNext + tilesPerGroup * 64u, sp.shardTiles * 64u);
-                        break;
-                    }
-                    band = (band + 1u) % 8u;
-                    if (++bandsTried >= 8u) { queueEmpty = true; break; }
-                }
-            }
-            if (poolNext != poolEnd && L.state == kIdle) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
-                const uint32_t s = poolNext + rank;
-                if (s < poolEnd) {
-                    const uint32_t tile = (s >> 6) * sp.shardWorld + sp.shardRank;
-                    const uint32_t inTile = s & 63u;
-                    const uint32_t px = (tile % sp.tilesX) * kTile + (inTile & 7u), py = (tile / sp.tilesX) * kTile + (inTile >> 3);
-                    if (tile < nTiles && px < sp.width && py < sp.height) {
-                        L.slot = s; L.k = 0;
-                        float4 acc = IDS ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[s];
-                        L.previous = mk(acc.x, acc.y, acc.z);
-                        L.state = kNewPath;
-                    }
-                }
-            }
-            if (poolNext != poolEnd) poolNext = min(poolEnd, poolNext + (uint32_t)__popcll(idleMask));
-        }
-
-        // ---- pick the most populated state (ballot + popcount, wave-uniform) ----
-        const int nNew = __popcll(__ballot(L.state == kNewPath));
+        // ---- pick what to run: the most populated of interior / leaf / feed (ballot + popcount, wave-uniform).
+        // "Feed" is everything the shading round serves: lanes with a finished traversal, lanes about to start
+        // a path, and idle lanes while pixels are left to hand out.
         const int nInt = __popcll(__ballot(L.state == kInterior));
         const int nLeaf = __popcll(__ballot(L.state == kLeaf));
-        const int nShade = __popcll(__ballot(L.state == kShade));
-        if ((nNew | nInt | nLeaf | nShade) == 0) {
-            if (queueEmpty && poolNext == poolEnd) break;      // every wave reaches this: the queues only shrink
-            continue;
-        }
-        const int most = max(max(nNew, nInt), max(nLeaf, nShade));
-        const bool runShade = nShade >= RT_SHADE_AT, runLeaf = !runShade && nLeaf >= RT_LEAF_AT;
+        const bool pixelsLeft = (poolNext != poolEnd) || !queueEmpty;
+        const int nFeed = __popcll(__ballot(L.state == kShade || L.state == kNewPath || (pixelsLeft && L.state == kIdle)));
+        if ((nInt | nLeaf | nFeed) == 0) break;      // every wave reaches this: the queues only shrink
+        const int most = max(nInt, max(nLeaf, nFeed));
+        const bool runFeed = nFeed >= RT_SHADE_AT, runLeaf = !runFeed && nLeaf >= RT_LEAF_AT;
 
-        if (nInt == most && !runShade && !runLeaf) {
+        if (COUNT) rc.start();
+        if (nInt == most && !runFeed && !runLeaf) {
             // the hot loop: stay in it while most of the lanes that entered are still descending
             int steps = 0;
             do {
@@ -393,56 +415,35 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                 if (L.state == kInterior) interior_step<COUNT>(sp, st, L, tl);
                 ++steps;
             } while (steps < RT_INT_STEPS && __popcll(__ballot(L.state == kInterior)) * RT_KEEP_DEN >= nInt * RT_KEEP_NUM);
-        } else if (runLeaf || (nLeaf == most && !runShade)) {
+            if (COUNT) rc.stop(1);
+        } else if (runLeaf || (nLeaf == most && !runFeed)) {
             if (COUNT) { tl.rounds[2] += (lane == 0); tl.lanes[2] += (L.state == kLeaf); }
             if (L.state == kLeaf) leaf_step<COUNT>(sp, st, L, tl);
-        } else if (nNew == most && !runShade) {
-            if (COUNT) { tl.rounds[0] += (lane == 0); tl.lanes[0] += (L.state == kNewPath); }
-            if (L.state == kNewPath) {
-                // F:461-462: per-frame jitter from the noise texture, primary ray
-                const FrameParams fp = frames[L.k];
-                const uint32_t tile = (L.slot >> 6) * sp.shardWorld + sp.shardRank, inTile = L.slot & 63u;
-                const float fx = (float)((tile % sp.tilesX) * kTile + (inTile & 7u)) + 0.5f;
-                const float fy = (float)((tile / sp.tilesX) * kTile + (inTile >> 3)) + 0.5f;
-                if (COUNT) tl.noise++;
-                V3 ro = sample_noise(sp, fp.seedY + 0.007f * 0.0f, fp.seedZ + 0.007f * 0.0f);
-                V3 pt = ((camPos + sp.vpD * facing) + (sp.vpW * (-0.5f + ((fx - 0.5f) + ro.x) / resx)) * U) +
-                        (vpH * (-0.5f + ((fy - 0.5f) + ro.y) / resy)) * Vd;
-                L.ray = MakeRay(camPos, normalize3(pt - camPos));
-                L.throughput = mk(1.0f, 1.0f, 1.0f);
-                L.bounce = 0; L.segments = 0;
-                hitNormal = mk(0.0f, 0.0f, 0.0f);          // a new invocation starts with a blank hit record
-                begin_traversal<COUNT>(sp, L, tl);
-            }
+            if (COUNT) rc.stop(2);
         } else {
+            // ================= shading round: shade, hand out pixels, start paths =================
             if (COUNT) { tl.rounds[3] += (lane == 0); tl.lanes[3] += (L.state == kShade); }
             if (L.state == kShade) {
                 if (COUNT) tl.pops += (uint32_t)L.iters;
+                const bool hitAnything = L.bestIdx >= 0;
+                bool done = false;          // path finished with colour `result`
+                V3 result = mk(0.0f, 0.0f, 0.0f);
+                FrameParams fp = {};
                 if (IDS) {
                     ids[(size_t)L.slot * 3 + 0] = L.bestIdx; ids[(size_t)L.slot * 3 + 1] = (int32_t)__float_as_uint(L.bestT);
                     ids[(size_t)L.slot * 3 + 2] = L.iters;
                     L.state = kIdle;
-                } else {
-                    const FrameParams fp = frames[L.k];
-                    const bool hitAnything = L.bestIdx >= 0;
+                } else if (BL < 2u) {
+                    // the two debug views
+                    if (SINGLE) fp = f0; else fp = frames[L.k];
                     if (COUNT && hitAnything) tl.hits++;
-                    V3 hitPoint = mk(0.0f, 0.0f, 0.0f), hitColour = mk(0.0f, 0.0f, 0.0f);
-                    bool frontFace = false;
-                    MaterialRec m;
                     if (hitAnything) {
-                        // the part of hitTriangle that only the accepted hit needs (F:235-238) + material (F:291)
                         const float4* T = reinterpret_cast<const float4*>(sp.tris + L.bestIdx);
                         float4 a = T[0], b4 = T[1], c = T[2];
                         V3 e1 = mk(a.w, b4.x, b4.y), e2 = mk(b4.z, b4.w, c.x);
-                        hitPoint = L.ray.o + (1.0f * L.bestT) * L.ray.d;
                         V3 n = normalize3(cross3(e1, e2));
-                        frontFace = dot3(L.ray.d, n) < 0.0f;
-                        hitNormal = frontFace ? n : -n;
-                        m = sp.materials[__float_as_int(c.y)];
-                        hitColour = mk(m.colour[0], m.colour[1], m.colour[2]);
+                        hitNormal = (dot3(L.ray.d, n) < 0.0f) ? n : -n;
                     }
-                    bool done = false;          // path finished with colour `result`
-                    V3 result = mk(0.0f, 0.0f, 0.0f);
                     if (BL == 0u) {
                         // BVH heat map, F:313-324,386-387
                         const int iters = L.iters;
@@ -450,30 +451,54 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                         if (iters < 64) { float g = (1.0f / 64.0f) * itf; result = mk(g, g, g); }
                         else if (iters < 128) { float kk = (float)(iters - 64); result = mk(1.0f - (0.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk); }
                         else { float kk = (float)(iters - 128); result = mk(1.0f - (1.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk); }
-                        done = true;
-                    } else if (BL == 1u) {
+                    } else {
                         result = abs3(hitNormal);                       // F:388-389
+                    }
+                    done = true;
+                } else {
+                    if (SINGLE) fp = f0; else fp = frames[L.k];
+                    if (COUNT && hitAnything) tl.hits++;
+                    const int i = L.bounce;
+                    // F:391-394
+                    uint32_t sx = Hashf(L.ray.o.x + L.ray.d.y) + Hash((uint32_t)i) + fp.hashX;
+                    uint32_t sy = Hashf(L.ray.o.y + L.ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
+                    float fsx = (float)sx, fsy = (float)sy;
+                    float seedx = (fsx - nresx * floorf(fsx / nresx)) / nresx;
+                    float seedy = (fsy - nresy * floorf(fsy / nresy)) / nresy;
+                    // What every lane of the round reads first is requested here, before any of it is used:
+                    // the hit triangle and the first noise footprint, or the sky footprint, share one memory
+                    // round trip. All lanes take part in both groups of requests (a lane that missed reads
+                    // triangle 0 and ignores it): no divergent branch separates request from use.
+                    float ta_w = 0.0f, tc_x = 0.0f, tc_y = 0.0f;      // (initialised so that nothing is carried between rounds)
+                    float4 tb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    Texels nA = {0u, 0u, 0u, 0u, 0, 0}, sk = {0u, 0u, 0u, 0u, 0, 0};
+                    if (__ballot(hitAnything) != 0ull) {
+                        const TriRec* T = sp.tris + (hitAnything ? L.bestIdx : 0);
+                        ta_w = T->e1x; tb = *reinterpret_cast<const float4*>(&T->e1y); tc_x = T->e2z; tc_y = __int_as_float(T->material);
+                        nA = fetch_noise(sp, seedx + 0.01534f, seedy + 0.183f);      // F:420
+                    }
+                    if (__ballot(!hitAnything) != 0ull) sk = fetch_sky(sp, L.ray.d);  // F:410-411
+                    if (!hitAnything) {
+                        if (COUNT) tl.sky += (i == 0) ? 2u : 1u;
+                        result = L.throughput * resolve3(sk);                        // F:410-413
                         done = true;
                     } else {
-                        const int i = L.bounce;
-                        // F:391-394
-                        uint32_t sx = Hashf(L.ray.o.x + L.ray.d.y) + Hash((uint32_t)i) + fp.hashX;
-                        uint32_t sy = Hashf(L.ray.o.y + L.ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
-                        float fsx = (float)sx, fsy = (float)sy;
-                        float seedx = (fsx - nresx * floorf(fsx / nresx)) / nresx;
-                        float seedy = (fsy - nresy * floorf(fsy / nresy)) / nresy;
-                        if (!hitAnything) {
-                            if (COUNT) tl.sky += (i == 0) ? 2u : 1u;
-                            result = L.throughput * sample_sky(sp, L.ray.d);     // F:410-413
-                            done = true;
-                        } else if (m.isLight) {
+                        // the part of hitTriangle that only the accepted hit needs (F:235-238) + material (F:291)
+                        V3 e1 = mk(ta_w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tc_x);
+                        V3 hitPoint = L.ray.o + (1.0f * L.bestT) * L.ray.d;
+                        V3 n = normalize3(cross3(e1, e2));
+                        const bool frontFace = dot3(L.ray.d, n) < 0.0f;
+                        hitNormal = frontFace ? n : -n;
+                        const MaterialRec m = lds_mat[__float_as_int(tc_y)];
+                        V3 hitColour = mk(m.colour[0], m.colour[1], m.colour[2]);
+                        if (m.isLight) {
                             result = (L.throughput * hitColour) * m.transparency;   // F:415-418
                             done = true;
                         } else {
                             V3 next;
                             int ii = i;
                             if (COUNT) tl.noise++;
-                            float trRng = sample_noise(sp, seedx + 0.01534f, seedy + 0.183f).x;   // F:420
+                            float trRng = resolve(nA, 0);
                             if (trRng < m.transparency) {
                                 // TransparentScatter, F:328-336
                                 const float AIR = 1.0003f;
@@ -484,10 +509,12 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                                 if (trRng < 0.5f) ii--;
                             } else {
                                 if (COUNT) tl.noise += 2;
-                                V3 n3 = sample_noise(sp, seedx - 0.062f, seedy - 0.0345f);       // F:426
+                                const Texels nB = fetch_noise(sp, seedx - 0.062f, seedy - 0.0345f);       // F:426
+                                const Texels nC = fetch_noise(sp, seedx, seedy);                          // F:428
+                                V3 n3 = resolve3(nB);
                                 V3 diffuseDir = normalize3(hitNormal + ((2.0f * n3) - mk(1.0f, 1.0f, 1.0f)) * m.roughness);
                                 V3 specularDir = reflect3(L.ray.d, hitNormal);
-                                bool isSpecular = sample_noise(sp, seedx, seedy).y < (1.0f - m.roughness);   // F:428
+                                bool isSpecular = resolve(nC, 1) < (1.0f - m.roughness);
                                 specularDir = mix3(specularDir, diffuseDir, m.roughness);
                                 next = isSpecular ? specularDir : diffuseDir;
                                 V3 spec = mk(m.specular[0], m.specular[1], m.specular[2]);
@@ -509,28 +536,87 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                             else begin_traversal<COUNT>(sp, L, tl);
                         }
                     }
-                    if (done) {
-                        // F:480-487
-                        V3 rgb = mk(0.0f, 0.0f, 0.0f) + result;
-                        rgb = rgb * (1.0f / 1.0f);
-                        L.previous = mix3(L.previous, rgb, fp.weight);
-                        if (COUNT) tl.paths++;
-                        ++L.k;
-                        if (L.k >= nFrames) {
-                            accum[L.slot] = make_float4(L.previous.x, L.previous.y, L.previous.z, 0.0f);
-                            L.state = kIdle;
-                        } else {
+                }
+                if (done) {
+                    // F:480-487
+                    V3 rgb = mk(0.0f, 0.0f, 0.0f) + result;
+                    rgb = rgb * (1.0f / 1.0f);
+                    L.previous = mix3(L.previous, rgb, fp.weight);
+                    if (COUNT) tl.paths++;
+                    ++L.k;
+                    if (L.k >= nFrames) {
+                        accum[L.slot] = make_float4(L.previous.x, L.previous.y, L.previous.z, 0.0f);
+                        L.state = kIdle;
+                    } else {
+                        L.state = kNewPath;
+                    }
+                }
+            }
+
+            // ---- hand waiting pixels to idle lanes ----
+            unsigned long long idleMask = __ballot(L.state == kIdle);
+            if (idleMask != 0ull) {
+                if (poolNext == poolEnd && !queueEmpty) {
+                    // pull the next group of tiles: one returning atomic by lane 0, broadcast to the wave
+                    for (;;) {
+                        uint32_t g = 0;
+                        if (lane == 0) g = atomicAdd(&queueHeads[band], 1u);
+                        g = __builtin_amdgcn_readfirstlane(g);
+                        const uint32_t first = band * bandSize;
+                        const uint32_t last = min(first + bandSize, nGroups);
+                        if (first + g < last) {
+                            poolNext = (first + g) * tilesPerGroup * 64u;
+                            poolEnd = min(poolNext + tilesPerGroup * 64u, sp.shardTiles * 64u);
+                            break;
+                        }
+                        band = (band + 1u) % 8u;
+                        if (++bandsTried >= 8u) { queueEmpty = true; break; }
+                    }
+                }
+                if (poolNext != poolEnd && L.state == kIdle) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
+                    const uint32_t s = poolNext + rank;
+                    if (s < poolEnd) {
+                        const uint32_t tile = (s >> 6) * sp.shardWorld + sp.shardRank;
+                        const uint32_t inTile = s & 63u;
+                        const uint32_t px = (tile % sp.tilesX) * kTile + (inTile & 7u), py = (tile / sp.tilesX) * kTile + (inTile >> 3);
+                        if (tile < nTiles && px < sp.width && py < sp.height) {
+                            L.slot = s; L.k = 0;
+                            float4 acc = IDS ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[s];
+                            L.previous = mk(acc.x, acc.y, acc.z);
                             L.state = kNewPath;
                         }
                     }
                 }
+                if (poolNext != poolEnd) poolNext = min(poolEnd, poolNext + (uint32_t)__popcll(idleMask));
             }
+
+            // ---- start paths: F:461-462 (pixel jitter precomputed per frame), primary ray ----
+            if (COUNT) { tl.rounds[0] += (lane == 0); tl.lanes[0] += (L.state == kNewPath); }
+            if (L.state == kNewPath) {
+                float jx, jy;
+                if (SINGLE) { jx = f0.jitterX; jy = f0.jitterY; } else { jx = frames[L.k].jitterX; jy = frames[L.k].jitterY; }
+                const uint32_t tile = (L.slot >> 6) * sp.shardWorld + sp.shardRank, inTile = L.slot & 63u;
+                const float fx = (float)((tile % sp.tilesX) * kTile + (inTile & 7u)) + 0.5f;
+                const float fy = (float)((tile / sp.tilesX) * kTile + (inTile >> 3)) + 0.5f;
+                if (COUNT) tl.noise++;
+                V3 pt = ((camPos + sp.vpD * facing) + (sp.vpW * (-0.5f + ((fx - 0.5f) + jx) / resx)) * U) +
+                        (vpH * (-0.5f + ((fy - 0.5f) + jy) / resy)) * Vd;
+                L.ray = MakeRay(camPos, normalize3(pt - camPos));
+                L.throughput = mk(1.0f, 1.0f, 1.0f);
+                L.bounce = 0; L.segments = 0;
+                hitNormal = mk(0.0f, 0.0f, 0.0f);          // a new invocation starts with a blank hit record
+                begin_traversal<COUNT>(sp, L, tl);
+            }
+            if (COUNT) rc.stop(3);
         }
     }
 
     // per-wave tallies: each wave owns one column (no atomics)
     uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths, tl.hits,
-                                    tl.rounds[0], tl.rounds[1], tl.rounds[2], tl.rounds[3], tl.lanes[0], tl.lanes[1], tl.lanes[2], tl.lanes[3]};
+                                    tl.rounds[0], tl.rounds[1], tl.rounds[2], tl.rounds[3], tl.lanes[0], tl.lanes[1], tl.lanes[2], tl.lanes[3],
+                                    lane == 0 ? (uint32_t)(rc.cycles[0] >> 6) : 0u, lane == 0 ? (uint32_t)(rc.cycles[1] >> 6) : 0u,
+                                    lane == 0 ? (uint32_t)(rc.cycles[2] >> 6) : 0u, lane == 0 ? (uint32_t)(rc.cycles[3] >> 6) : 0u};
     for (int s = 0; s < (int)kCounterSlots; ++s) {
         if (!COUNT && s != (int)kRays) continue;
         uint32_t v = vals[s];
@@ -583,9 +669,13 @@ uint32_t ResidentWaves() {
     int dev = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false>, 64, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false, true>, 64, 0) != hipSuccess) return 0;
     if (perCu < 1) perCu = 1;
     return (uint32_t)cus * (uint32_t)perCu;
+}
+
+void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames) {
+    hipLaunchKernelGGL(prepare_frames_kernel, dim3((nFrames + 63u) / 64u), dim3(64), 0, st, sp, frames, nFrames);
 }
 
 void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
@@ -594,9 +684,14 @@ void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const Sc
     float4* a = static_cast<float4*>(accum);
     uint2* sa = static_cast<uint2*>(spillArea);
     dim3 grid(nWaves), block(64);
-    if (ids) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride);
-    else if (count) hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride);
-    else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride);
+    const bool single = nFrames == 1u;
+#define RT_LAUNCH(C, I, S) hipLaunchKernelGGL((trace_kernel<C, I, S>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride)
+    if (ids) RT_LAUNCH(true, true, true);
+    else if (count && single) RT_LAUNCH(true, false, true);
+    else if (count) RT_LAUNCH(true, false, false);
+    else if (single) RT_LAUNCH(false, false, true);
+    else RT_LAUNCH(false, false, false);
+#undef RT_LAUNCH
 }
 
 void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots) {
