@@ -174,12 +174,13 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
     if (!c) return RT_ERR_INVALID;
     if ((nTri && (!tri12 || !matIdx)) || (nNode && !node8)) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: NULL array");
     if (nTri >= (1u << 24)) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: %u triangles; indices travel as floats and are exact only below 2^24", nTri);
+    if (nNode >= (1u << 24)) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: %u nodes; indices travel as floats and are exact only below 2^24", nNode);
     HIP_TRY(c, hipSetDevice(c->device));
 
     // ---- validate the pre-order tree and measure its depth (iteratively; no recursion) ----
     struct Info { int count; int ref; };
     auto info = [&](uint32_t i) { Info r; r.count = (int)node8[(size_t)i * 8 + 6]; r.ref = (int)node8[(size_t)i * 8 + 7]; return r; };
-    std::vector<NodeRec> nodes(nNode);
+    std::vector<NodeRec> nodes;
     int maxInteriorDepth = 0;
     if (nNode) {
         std::vector<std::pair<uint32_t, int>> todo;   // (node, depth), root depth 1
@@ -205,17 +206,26 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
             }
         }
         (void)visited;
-        // ---- re-lay-out: one 64-byte record per interior node ----
-        auto childRef = [&](uint32_t child) { Info in = info(child); return in.count > 0 ? MakeLeafRef((uint32_t)in.ref, (uint32_t)in.count) : child; };
+        // ---- re-lay-out: one 64-byte record per interior node, interior nodes numbered consecutively in
+        // the reference's pre-order (a node's left child, when interior, is the next record); an interior
+        // child is referenced by its record's byte offset ----
+        std::vector<uint32_t> recordOf(nNode, 0);
+        uint32_t nInterior = 0;
+        for (uint32_t i = 0; i < nNode; ++i)
+            if (seen[i] && info(i).count == 0) recordOf[i] = nInterior++;
+        nodes.assign(nInterior, NodeRec{});
+        auto childRef = [&](uint32_t child) {
+            Info in = info(child);
+            return in.count > 0 ? MakeLeafRef((uint32_t)in.ref, (uint32_t)in.count) : recordOf[child] * (uint32_t)sizeof(NodeRec);
+        };
         auto copyBox = [&](uint32_t child, float* mn, float* mx) {
             const float* p = node8 + (size_t)child * 8;
             for (int k = 0; k < 3; ++k) { mx[k] = p[k]; mn[k] = p[3 + k]; }
         };
         for (uint32_t i = 0; i < nNode; ++i) {
-            NodeRec& r = nodes[i];
-            std::memset(&r, 0, sizeof r);
             Info in = info(i);
-            if (in.count > 0 || !seen[i]) { r.leftRef = r.rightRef = kNoRef; continue; }
+            if (in.count > 0 || !seen[i]) continue;
+            NodeRec& r = nodes[recordOf[i]];
             copyBox(i + 1, r.lmin, r.lmax);
             copyBox((uint32_t)in.ref, r.rmin, r.rmax);
             r.leftRef = childRef(i + 1); r.rightRef = childRef((uint32_t)in.ref);
@@ -240,9 +250,9 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->dNodes) { (void)hipFree(c->dNodes); c->dNodes = nullptr; }
     if (c->dTris) { (void)hipFree(c->dTris); c->dTris = nullptr; }
-    if (nNode) {
-        HIP_TRY(c, hipMalloc((void**)&c->dNodes, sizeof(NodeRec) * nNode));
-        HIP_TRY(c, hipMemcpy(c->dNodes, nodes.data(), sizeof(NodeRec) * nNode, hipMemcpyHostToDevice));
+    if (!nodes.empty()) {
+        HIP_TRY(c, hipMalloc((void**)&c->dNodes, sizeof(NodeRec) * nodes.size()));
+        HIP_TRY(c, hipMemcpy(c->dNodes, nodes.data(), sizeof(NodeRec) * nodes.size(), hipMemcpyHostToDevice));
     }
     if (nTri) {
         HIP_TRY(c, hipMalloc((void**)&c->dTris, sizeof(TriRec) * nTri));

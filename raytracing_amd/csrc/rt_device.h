@@ -1,12 +1,13 @@
 // Device-side data layout shared by the HIP kernels and the host side of the C ABI.
 //
 // HBM layout (all arrays 256-byte aligned by hipMalloc):
-//   nodes   NodeRec[nNode]   64 B per INTERIOR node, indexed by the reference's pre-order node
-//                            number. A record carries the boxes of BOTH children plus what each
-//                            child is, so one 64-byte fetch (4 x dwordx4, one cache line half)
-//                            replaces the reference's three 32-byte fetches per visited node
-//                            (node + two children, Fragment.glsl:278,298-299) and a leaf is
-//                            never fetched at all: its triangle range travels in the child ref.
+//   nodes   NodeRec[nInterior] 64 B per INTERIOR node, in the reference's pre-order with the leaves
+//                            left out (so a node's left child, when interior, is the next record).
+//                            A record carries the boxes of BOTH children plus what each child is,
+//                            so one 64-byte fetch (4 x dwordx4, one cache line half) replaces the
+//                            reference's three 32-byte fetches per visited node (node + two
+//                            children, Fragment.glsl:278,298-299) and a leaf is never fetched at
+//                            all: its triangle range travels in the child ref.
 //   tris    TriRec[nTri]     48 B per triangle in leaf order: v0, e1 = v1-v0, e2 = v2-v0 (the
 //                            same fp32 subtractions the shader does per test, done once), and
 //                            the material slot.
@@ -31,7 +32,8 @@ constexpr uint32_t kNoRef = 0x7fffffffu; // "no node"
 // segments; the parity oracle applies the same bound.
 constexpr uint32_t kMaxSegments = 4096;
 
-// child reference: interior -> node index (>= 0); leaf -> kLeafBit | (count-1) << 27 | triStart
+// child reference: interior -> byte offset of the child's record in `nodes` (< 2^31);
+//                  leaf -> kLeafBit | (count-1) << 27 | triStart
 __host__ __device__ inline uint32_t MakeLeafRef(uint32_t triStart, uint32_t count) {
     return kLeafBit | ((count - 1u) << 27) | triStart;
 }

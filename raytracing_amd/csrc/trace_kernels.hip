@@ -187,7 +187,7 @@ enum LaneState : int { kIdle = 0, kNewPath = 1, kInterior = 2, kLeaf = 3, kShade
 #define RT_LEAF_AT 64      // run the leaf code as soon as this many lanes wait for it (64 = only when it is the biggest group)
 #endif
 #ifndef RT_SHADE_AT
-#define RT_SHADE_AT 64
+#define RT_SHADE_AT 24
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 5
@@ -213,7 +213,8 @@ struct Lane {
 
 struct StackRef {
     uint2* lds;                 // this lane's LDS column, stride 64 entries
-    unsigned long long* spill;  // this lane's HBM column, stride 64 (entries kLdsStack .. kMaxStack-1)
+    unsigned long long* spill;  // this wave's HBM area (wave-uniform): entry e of lane l at [(e - kLdsStack) * 64 + l]
+    uint32_t lane;
 };
 
 // The two halves of the stack are accessed with different value types on purpose: with equal
@@ -222,7 +223,7 @@ struct StackRef {
 // memory path.
 __device__ __forceinline__ void push(const StackRef& st, int& top, uint32_t ref, float t) {
     if (top < kLdsStack) st.lds[top * 64] = make_uint2(ref, __float_as_uint(t));
-    else st.spill[(top - kLdsStack) * 64] = ((unsigned long long)__float_as_uint(t) << 32) | ref;
+    else st.spill[(uint32_t)(top - kLdsStack) * 64u + st.lane] = ((unsigned long long)__float_as_uint(t) << 32) | ref;
     ++top;
 }
 
@@ -235,7 +236,7 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
         --L.top;
         uint2 e = st.lds[min(L.top, kLdsStack - 1) * 64];
         if (L.top >= kLdsStack) {
-            unsigned long long w = st.spill[(L.top - kLdsStack) * 64];
+            unsigned long long w = st.spill[(uint32_t)(L.top - kLdsStack) * 64u + st.lane];
             e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
         }
         L.iters++;
@@ -263,26 +264,27 @@ __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, 
     }
 }
 
-// One interior node: both children from one 64-byte record, F:296-311.
+// One interior node: both children from one 64-byte record, F:296-311. An interior reference is the
+// record's byte offset, so the address is the (scalar) array base plus a 32-bit lane offset.
 template <bool COUNT>
 __device__ __forceinline__ void interior_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
-    const float4* N = reinterpret_cast<const float4*>(sp.nodes + L.cur);
-    float4 n0 = N[0], n1 = N[1], n2 = N[2], n3 = N[3];
+    const float4* N = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sp.nodes) + L.cur);
+    float4 n0 = N[0], n1 = N[1], n2 = N[2];
+    const uint2 refs = *reinterpret_cast<const uint2*>(N + 3);      // 56 of the record's 64 bytes are read
     if (COUNT) tl.boxes += 2;
     float tL, tR;
     bool hL = hit_box(L.ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tL);
     bool hR = hit_box(L.ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tR);
-    uint32_t refL = __float_as_uint(n3.x), refR = __float_as_uint(n3.y);
-    bool okL = hL && tL < L.bestT, okR = hR && tR < L.bestT;
-    // the child pushed last is popped next; `tL < tR` decides which one that is
-    bool leftFirst = tL < tR;
-    uint32_t nearRef = leftFirst ? refL : refR, farRef = leftFirst ? refR : refL;
-    float farT = leftFirst ? tR : tL;
-    bool okNear = leftFirst ? okL : okR, okFar = leftFirst ? okR : okL;
-    if (okNear | okFar) {
-        if (okNear & okFar) push(st, L.top, farRef, farT);
+    const uint32_t refL = refs.x, refR = refs.y;
+    const bool okL = hL && tL < L.bestT, okR = hR && tR < L.bestT;
+    // The reference pushes both children and pops the one pushed last: the left one when tL < tR.
+    // Here the child visited next is taken directly and only the other one is deferred.
+    const bool leftFirst = tL < tR;
+    if (okL || okR) {
+        if (okL && okR) push(st, L.top, leftFirst ? refR : refL, leftFirst ? tR : tL);
         L.iters++;               // the immediate pop of the chosen child (its test passes: bestT is unchanged)
-        L.cur = okNear ? nearRef : farRef;
+        const bool takeLeft = okL && (leftFirst || !okR);
+        L.cur = takeLeft ? refL : refR;
         L.state = (L.cur & kLeafBit) ? kLeaf : kInterior;
     } else {
         pop_next<COUNT>(st, L);
@@ -291,8 +293,8 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
 
 // hitTriangle, F:207-234: the distance at which L.ray meets triangle (v0, e1, e2), accepted only if
 // it passes the shader's four early returns (with its comparison operators: NaNs fall through them).
-__device__ __forceinline__ bool hit_triangle(const Ray& r, float4 a, float4 b, float4 c, float& t) {
-    V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, c.x);
+__device__ __forceinline__ bool hit_triangle(const Ray& r, float4 a, float4 b, float e2z, float& t) {
+    V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, e2z);
     V3 h = cross3(r.d, e2);
     float det = dot3(e1, h);
     float invDet = 1.0f / det;
@@ -313,12 +315,13 @@ template <bool COUNT>
 __device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
     const uint32_t first = L.cur & 0x07ffffffu, count = ((L.cur >> 27) & 15u) + 1u;
     const uint32_t last = first + count - 1u;
+    // 36 of a triangle record's 48 bytes are read here (the material slot only matters for the accepted hit)
     const float4* T0 = reinterpret_cast<const float4*>(sp.tris + first);
     const float4* T1 = reinterpret_cast<const float4*>(sp.tris + min(first + 1u, last));
     const float4* T2 = reinterpret_cast<const float4*>(sp.tris + min(first + 2u, last));
-    float4 a0 = T0[0], b0 = T0[1], c0 = T0[2];
-    float4 a1 = T1[0], b1 = T1[1], c1 = T1[2];
-    float4 a2 = T2[0], b2 = T2[1], c2 = T2[2];
+    float4 a0 = T0[0], b0 = T0[1]; float c0 = T0[2].x;
+    float4 a1 = T1[0], b1 = T1[1]; float c1 = T1[2].x;
+    float4 a2 = T2[0], b2 = T2[1]; float c2 = T2[2].x;
     if (COUNT) tl.tris += count;
     float t;
     if (hit_triangle(L.ray, a0, b0, c0, t) && L.bestT > t) { L.bestT = t; L.bestIdx = (int)first; }
@@ -326,7 +329,7 @@ __device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef&
     if (hit_triangle(L.ray, a2, b2, c2, t) && count > 2u && L.bestT > t) { L.bestT = t; L.bestIdx = (int)first + 2; }
     for (uint32_t i = first + 3u; i <= last; ++i) {
         const float4* T = reinterpret_cast<const float4*>(sp.tris + i);
-        if (hit_triangle(L.ray, T[0], T[1], T[2], t) && L.bestT > t) { L.bestT = t; L.bestIdx = (int)i; }
+        if (hit_triangle(L.ray, T[0], T[1], T[2].x, t) && L.bestT > t) { L.bestT = t; L.bestIdx = (int)i; }
     }
     pop_next<COUNT>(st, L);
 }
@@ -356,7 +359,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
     const uint32_t lane = threadIdx.x;
     StackRef st;
     st.lds = lds_stack + lane;
-    st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64 + lane;
+    st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64;
+    st.lane = lane;
 
     // the material table is small and read at every hit: keep a copy in LDS
     for (uint32_t j = lane; j < (uint32_t)(sizeof(MaterialRec) / 4 * kMaxMaterials); j += 64u)
