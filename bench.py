@@ -82,7 +82,7 @@ def cpu_baseline(sc, noise, sky, bl, W, H):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from rt_oracle import Oracle
     cores = min(16, os.cpu_count() or 1)
-    w, h, frames = W // 4, H // 4, 2
+    w, h, frames = W // 2, H // 2, 12      # about 10-15 s of work for 16 threads on the 4K workload
     o = Oracle(w, h, threads=cores)
     o.set_scene(sc.tri12, sc.matidx, sc.node8)
     o.set_materials(sc.materials[:16])
@@ -243,6 +243,8 @@ def main():
                 traffic = t.get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "note": "algorithmic bytes (what the reference shader fetches) are mostly cache hits here: frac > 1 means the "
+                            "kernel is not HBM-bound; 'traffic' is the measured memory-side bytes per launch",
                     "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(per_launch),
                     "bytes_per_ray": round(algorithmic_bytes(ci) / ci["rays"], 1),

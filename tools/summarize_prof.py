@@ -3,6 +3,7 @@
 import collections
 import csv
 import glob
+import json
 import os
 import sys
 
@@ -35,8 +36,11 @@ v = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
     rows = [r for r in csv.DictReader(open(f)) if "trace_kernel" in r["Kernel_Name"]]
     n = max(1, len(set(r["Dispatch_Id"] for r in rows)))
+    here = collections.defaultdict(float)
     for r in rows:
-        v[r["Counter_Name"]] = v.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"]) / n
+        here[r["Counter_Name"]] += float(r["Counter_Value"]) / n
+    for k, val in here.items():
+        v.setdefault(k, val)         # a counter collected in several passes is taken from the first one
 lines.append("")
 lines.append("## derived")
 if "SQ_THREAD_CYCLES_VALU" in v:
@@ -55,6 +59,18 @@ if "FETCH_SIZE" in v:
 if "WRITE_SIZE" in v:
     lines.append("WRITE_SIZE             = %.4g KB per dispatch" % v["WRITE_SIZE"])
 os.makedirs("profiles", exist_ok=True)
+if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    # rocprofv3 reports both in KB. On gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes, so reads of
+    # 16 bytes per lane are doubled; WRITE_SIZE is exact. Both count requests on the memory side of the L2, Infinity
+    # Cache hits included, so the sum is an upper bound on what reached HBM.
+    bench = json.loads(open(os.path.join(src, "plain.json")).read().strip().splitlines()[-1])
+    fetch = v["FETCH_SIZE"] * 1024.0 * 2.0
+    write = v["WRITE_SIZE"] * 1024.0
+    traffic = {"workload": bench["config"]["workload"], "hbm_bytes_per_launch": int(fetch + write),
+               "fetch_bytes_per_launch": int(fetch), "write_bytes_per_launch": int(write), "profile": tag,
+               "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per trace_kernel dispatch; memory-side L2 requests, Infinity-Cache hits included"}
+    json.dump(traffic, open(os.path.join("profiles", "hbm_traffic.json"), "w"), indent=1)
+    lines.append("memory-side traffic    = %.3f GB per dispatch (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes)" % ((fetch + write) / 1e9))
 out = os.path.join("profiles", tag + "_summary.txt")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[-12:]))
