@@ -352,8 +352,10 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                                                    float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
                                                    int32_t* __restrict__ ids /* IDS only: [slot][3] */,
                                                    uint2* __restrict__ spillArea /* [gridDim.x][kMaxStack-kLdsStack][64] */,
-                                                   uint32_t* __restrict__ queueHeads /* [8] next group per band, zeroed before the launch */,
-                                                   uint32_t nGroups, uint32_t tilesPerGroup, uint32_t tallyStride) {
+                                                   uint32_t* __restrict__ queueHeads /* [8] next tile per band, zeroed before the launch */,
+                                                   uint32_t nGroups /* tiles of this shard */, uint32_t tallyStride,
+                                                   const uint32_t* __restrict__ order /* [nGroups] tile hand-out order, or NULL for 0,1,2.. */,
+                                                   uint32_t* __restrict__ tileCost /* [nGroups] rays traced per tile are added here, or NULL */) {
     __shared__ uint2 lds_stack[kLdsStack * 64];
     __shared__ MaterialRec lds_mat[kMaxMaterials];
     const uint32_t lane = threadIdx.x;
@@ -381,9 +383,10 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
     FrameParams f0 = {};
     if (SINGLE) f0 = frames[0];
 
-    // Groups of consecutive tiles are queued in 8 bands; a wave drains the band with its
-    // blockIdx % 8 label first (waves with equal labels share an XCD, hence an L2), then helps
-    // the other bands. Which band a wave starts on only affects speed.
+    // Tiles are queued in 8 bands of consecutive positions of the hand-out order (with the order the host
+    // builds, a band is a contiguous eighth of the shard, most expensive tiles first); a wave drains the band
+    // with its blockIdx % 8 label first (waves with equal labels share an XCD, hence an L2), then helps the
+    // other bands. Which tile a wave gets when only affects speed: a pixel's result does not depend on it.
     const uint32_t bandSize = (nGroups + 7u) / 8u;
     uint32_t band = blockIdx.x % 8u, bandsTried = 0;
     uint32_t poolNext = 0, poolEnd = 0;       // wave-uniform: slots [poolNext, poolEnd) wait for a lane
@@ -547,6 +550,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                     rgb = rgb * (1.0f / 1.0f);
                     L.previous = mix3(L.previous, rgb, fp.weight);
                     if (COUNT) tl.paths++;
+                    // what this path cost, for the next launches' hand-out order (no value returned: fire and forget)
+                    if (tileCost) __hip_atomic_fetch_add(&tileCost[L.slot >> 6], L.segments + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ++L.k;
                     if (L.k >= nFrames) {
                         accum[L.slot] = make_float4(L.previous.x, L.previous.y, L.previous.z, 0.0f);
@@ -569,8 +574,10 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                         const uint32_t first = band * bandSize;
                         const uint32_t last = min(first + bandSize, nGroups);
                         if (first + g < last) {
-                            poolNext = (first + g) * tilesPerGroup * 64u;
-                            poolEnd = min(poolNext + tilesPerGroup * 64u, sp.shardTiles * 64u);
+                            uint32_t t = first + g;
+                            if (order) t = order[t];
+                            poolNext = t * 64u;
+                            poolEnd = poolNext + 64u;
                             break;
                         }
                         band = (band + 1u) % 8u;
@@ -629,6 +636,18 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
     }
 }
 
+// Sort keys for the tile hand-out order: band first (a contiguous eighth of the shard, so that neighbouring
+// tiles stay on one XCD), then descending cost. Clears the cost array for the next period.
+__global__ void order_keys_kernel(uint32_t* __restrict__ tileCost, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                  uint32_t nTiles, uint32_t bandSize) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nTiles) return;
+    const uint32_t cost = min(tileCost[i], 0x3ffffffu);
+    keys[i] = ((i / bandSize) << 26) | (0x3ffffffu - cost);
+    vals[i] = i;
+    tileCost[i] = 0u;
+}
+
 // Sums the per-tile tallies into 64-bit totals: out[slot] += sum(tally[slot][*]); clears tally.
 __global__ void reduce_tally_kernel(uint32_t* __restrict__ tally, uint32_t nTiles, unsigned long long* __restrict__ out) {
     const int slot = blockIdx.x;
@@ -684,18 +703,23 @@ void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* fra
 
 void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
                  void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
-                 uint32_t tilesPerGroup) {
+                 const uint32_t* order, uint32_t* tileCost) {
     float4* a = static_cast<float4*>(accum);
     uint2* sa = static_cast<uint2*>(spillArea);
     dim3 grid(nWaves), block(64);
     const bool single = nFrames == 1u;
-#define RT_LAUNCH(C, I, S) hipLaunchKernelGGL((trace_kernel<C, I, S>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tilesPerGroup, tallyStride)
+#define RT_LAUNCH(C, I, S) hipLaunchKernelGGL((trace_kernel<C, I, S>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost)
     if (ids) RT_LAUNCH(true, true, true);
     else if (count && single) RT_LAUNCH(true, false, true);
     else if (count) RT_LAUNCH(true, false, false);
     else if (single) RT_LAUNCH(false, false, true);
     else RT_LAUNCH(false, false, false);
 #undef RT_LAUNCH
+}
+
+void LaunchOrderKeys(hipStream_t st, uint32_t* tileCost, uint32_t* keys, uint32_t* vals, uint32_t nTiles) {
+    const uint32_t bandSize = (nTiles + 7u) / 8u;
+    hipLaunchKernelGGL(order_keys_kernel, dim3((nTiles + 255u) / 256u), dim3(256), 0, st, tileCost, keys, vals, nTiles, bandSize);
 }
 
 void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots) {
