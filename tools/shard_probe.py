@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times one rank's share of the benchmark frame on one GPU: shard 0 of WORLD (what each of WORLD GPUs would trace).
 Usage: python3 tools/shard_probe.py [workload]"""
-import os, sys
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import raytracing_amd as ra
@@ -16,12 +16,14 @@ for world in (1, 2, 4, 8):
     for k in range(2):
         r.render(k, seeds[k:k + 1])
     r.sync(); r.counters(reset=True); r.kernel_time(reset=True)
+    t0 = time.perf_counter()
     for k in range(2, 12):
         r.render(k, seeds[k:k + 1])
     r.sync()
+    wall = (time.perf_counter() - t0) * 1e3 / 10
     ms, n = r.kernel_time(reset=True); rays = r.counters()["rays"]
-    print("world %d: %7.3f ms per frame on one rank  (ideal %7.3f)  %7.1f Mrays/s per rank" % (
-        world, ms / n, ms / n if world == 1 else base / world, rays / ms / 1e3))
+    print("world %d: %7.3f ms per frame on one rank  (ideal %7.3f)  %7.1f Mrays/s per rank   wall %7.3f ms per frame (+%.0f us over the kernel)" % (
+        world, ms / n, ms / n if world == 1 else base / world, rays / ms / 1e3, wall, (wall - ms / n) * 1e3))
     if world == 1:
         base = ms / n
     r.close()
