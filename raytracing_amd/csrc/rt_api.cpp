@@ -281,6 +281,9 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
     }
 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // from here until the new arrays are in place the context has no scene (a failed allocation must not leave
+    // the old, freed arrays reachable)
+    c->haveScene = false; c->sp.nodes = nullptr; c->sp.tris = nullptr; c->sp.rootRef = kNoRef; c->sp.nNode = 0;
     if (c->dNodes) { (void)hipFree(c->dNodes); c->dNodes = nullptr; }
     if (c->dTris) { (void)hipFree(c->dTris); c->dTris = nullptr; }
     if (!nodes.empty()) {
@@ -340,6 +343,7 @@ int rt_set_noise(rt_context* c, const uint8_t* rgb, uint32_t w, uint32_t h) {
     std::vector<uint32_t> px((size_t)w * h);
     for (size_t i = 0; i < px.size(); ++i) px[i] = (uint32_t)rgb[3 * i] | ((uint32_t)rgb[3 * i + 1] << 8) | ((uint32_t)rgb[3 * i + 2] << 16);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->haveNoise = false; c->sp.noise = nullptr;
     if (c->dNoise) { (void)hipFree(c->dNoise); c->dNoise = nullptr; }
     HIP_TRY(c, hipMalloc((void**)&c->dNoise, px.size() * 4));
     HIP_TRY(c, hipMemcpy(c->dNoise, px.data(), px.size() * 4, hipMemcpyHostToDevice));
@@ -355,6 +359,7 @@ int rt_set_skybox(rt_context* c, const uint8_t* const faces[6], uint32_t size) {
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = (size_t)size * size;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->haveSky = false; c->sp.sky = nullptr;
     if (c->dSky) { (void)hipFree(c->dSky); c->dSky = nullptr; }
     HIP_TRY(c, hipMalloc((void**)&c->dSky, n * 6 * 4));
     for (int f = 0; f < 6; ++f) HIP_TRY(c, hipMemcpy(c->dSky + n * f, faces[f], n * 4, hipMemcpyHostToDevice));
@@ -365,6 +370,7 @@ int rt_set_skybox(rt_context* c, const uint8_t* const faces[6], uint32_t size) {
 
 int rt_accum_clear(rt_context* c) {
     if (!c) return RT_ERR_INVALID;
+    if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_accum_clear: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->dAccum, 0, (size_t)c->sp.shardTiles * 64 * 16, c->stream));
     return RT_OK;
@@ -373,6 +379,7 @@ int rt_accum_clear(rt_context* c) {
 int rt_accum_write(rt_context* c, const float* rgba) {
     if (!c || !rgba) return c ? Fail(c, RT_ERR_INVALID, "rt_accum_write: NULL image") : RT_ERR_INVALID;
     if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_accum_write: only on an unsharded context");
+    if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_accum_write: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(c->dLinear, rgba, (size_t)c->width * c->height * 16, hipMemcpyHostToDevice, c->stream));
     LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, true);
@@ -384,6 +391,7 @@ int rt_accum_write(rt_context* c, const float* rgba) {
 int rt_accum_read(rt_context* c, float* rgba) {
     if (!c || !rgba) return c ? Fail(c, RT_ERR_INVALID, "rt_accum_read: NULL image") : RT_ERR_INVALID;
     if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_accum_read: sharded context; gather the shards and call rt_accum_assemble on an unsharded one");
+    if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_accum_read: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
     LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, false);
     HIP_TRY(c, hipGetLastError());
@@ -414,6 +422,7 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
 }
 
 static int CheckRenderable(rt_context* c, const char* who) {
+    if (!c->dAccum || !c->dTileCost || !c->dOrderVals || !c->dSortTemp) return Fail(c, RT_ERR_STATE, "%s: no accumulation buffers (rt_set_shard failed earlier)", who);
     if (!c->haveNoise) return Fail(c, RT_ERR_STATE, "%s: no noise texture (rt_set_noise)", who);
     if (!c->haveSky) return Fail(c, RT_ERR_STATE, "%s: no skybox (rt_set_skybox)", who);
     if (!c->haveScene) return Fail(c, RT_ERR_STATE, "%s: no scene (rt_scene_upload)", who);
@@ -519,6 +528,7 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) {
 int rt_postprocess(rt_context* c, int bloom_on, float* rgba_out, uint8_t* rgb8_out) {
     if (!c) return RT_ERR_INVALID;
     if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_postprocess: only on an unsharded context");
+    if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_postprocess: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
     LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, false);
     HIP_TRY(c, hipGetLastError());
@@ -584,6 +594,7 @@ int rt_shard_device_ptr(rt_context* c, void** p) {
 
 int rt_shard_export(rt_context* c, void* dstDevice) {
     if (!c || !dstDevice) return c ? Fail(c, RT_ERR_INVALID, "rt_shard_export: NULL destination") : RT_ERR_INVALID;
+    if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_shard_export: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(dstDevice, c->dAccum, (size_t)c->sp.shardTiles * 64 * 16, hipMemcpyDeviceToDevice, c->stream));
     return RT_OK;
@@ -592,6 +603,7 @@ int rt_shard_export(rt_context* c, void* dstDevice) {
 int rt_accum_assemble(rt_context* c, const void* gatheredDevice, uint32_t world) {
     if (!c || !gatheredDevice || world == 0) return c ? Fail(c, RT_ERR_INVALID, "rt_accum_assemble: bad argument") : RT_ERR_INVALID;
     if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_accum_assemble: the assembling context must be unsharded");
+    if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_accum_assemble: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t nTiles = c->sp.tilesX * c->sp.tilesY, per = (nTiles + world - 1) / world;
     LaunchUntile(c->stream, gatheredDevice, c->dLinear, c->width, c->height, c->sp.tilesX, world, per, false);

@@ -136,3 +136,24 @@ def test_errors_are_reported_not_fatal():
     with pytest.raises(ra.RtError):
         g.set_materials(np.zeros((17, 11), np.float32))
     g.close()
+
+
+def test_reupload_on_one_context_equals_fresh_context():
+    """State is replaced, not merged: after another scene, noise texture and sky have been uploaded and rendered,
+    uploading the first ones again gives the image a fresh context gives."""
+    W, H = 96, 56
+    a_scene, b_scene = make_scene("lightbox"), make_scene("teapot_like", target_tris=12000)
+    other_noise, other_sky = scenes.noise_texture(40, 24), scenes.sky_cubemap(16)
+    fresh = ra.Renderer(W, H)
+    setup(fresh, a_scene, NOISE, SKY)
+    fresh.render(0, SEEDS[:3])
+    want = fresh.read_accum()
+    fresh.close()
+    r = ra.Renderer(W, H)
+    setup(r, b_scene, other_noise, other_sky, bounce_limit=8)
+    r.render(0, SEEDS[:2])
+    setup(r, a_scene, NOISE, SKY)            # bounce limit back to 4 as well
+    r.clear()
+    r.render(0, SEEDS[:3])
+    assert differing_pixels(r.read_accum(), want) == 0
+    r.close()
