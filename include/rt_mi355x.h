@@ -69,8 +69,9 @@ typedef struct rt_counters {
     uint64_t sky_fetches;    /* texture(u_Skybox, ...) calls */
     uint64_t paths;          /* pixel samples finished */
     uint64_t hits;           /* rays that hit a triangle (full counting only) */
-    /* wave scheduler statistics (full counting only), per lane state new-path / interior / leaf / shade:
-     * rounds a wave spent in that state's code, and how many of its 64 lanes took part */
+    /* wave scheduler statistics (full counting only), indexed 0 path starts / 1 interior / 2 leaf / 3 shade:
+     * rounds a wave spent in that code and how many of its 64 lanes took part. Path starts run inside the shading
+     * round (after shading and the hand-out of pixels), so rounds[0] == rounds[3] and cycles[0] is 0. */
     uint64_t sched_rounds[4];
     uint64_t sched_lanes[4];
     uint64_t sched_cycles[4];   /* shader clock cycles the waves spent in those rounds (in units of 64 cycles) */

@@ -5,8 +5,9 @@
 // as that shader evaluates it under Mesa llvmpipe: reversed three-term dot products, normalize as
 // multiply by 1/sqrt, mix as a + t*(b-a), IEEE division and square root, denormals flushed, and
 // llvmpipe's 8-bit fixed-point bilinear texture filter. This file must be compiled with
-// -ffp-contract=off -fgpu-flush-denormals-to-zero (see Makefile); results are then bit-identical
-// to the CPU parity oracle, and per-pixel results do not depend on how pixels are scheduled.
+// -ffp-contract=off -fgpu-flush-denormals-to-zero (see Makefile; -fno-slp-vectorize is for speed
+// only); results are then bit-identical to the CPU parity oracle, and per-pixel results do not
+// depend on how pixels are scheduled.
 //
 // HOW it is computed is specific to this hardware:
 //   * BVH: 64-byte records hold both children of an interior node, leaves are encoded in the
@@ -16,13 +17,19 @@
 //   * The near child is descended into directly; only the far child goes to a stack whose first
 //     kLdsStack entries live in LDS as [entry][lane] (conflict-free: each lane owns a column,
 //     8-byte entries) and whose rare deeper entries spill to a per-wave HBM area.
-//   * Persistent waves: the grid is sized to the machine, each wave pulls groups of 8x8-pixel
-//     tiles from per-XCD queues (one returning atomic per group; neighbouring tiles stay on one
-//     XCD's L2), and a lane that finishes a pixel takes the next pixel of the wave's pool at once.
-//   * Wave-level scheduling by ballot: every lane is in one of four states (new path, interior
-//     node, leaf, shade); each round the wave runs the body of the most populated state, so the
-//     long interior-node loop, the triangle tests and the material code each run with many lanes
-//     instead of every round executing all three for a few lanes each.
+//   * Persistent waves: the grid is sized to the machine, each wave pulls one 8x8-pixel tile at a
+//     time from per-XCD queues (one returning atomic per tile; neighbouring tiles stay on one
+//     XCD's L2; the queues hand out the tiles that were most expensive in earlier launches first),
+//     and a lane that finishes a pixel takes the next pixel of the wave's tile at once.
+//   * Wave-level scheduling by ballot: a lane is descending (interior node), at a leaf, or waiting
+//     for the "feed" body (shade a finished traversal, hand out pixels, start paths); each round the
+//     wave runs the body of the most populated group, so the long interior-node loop, the triangle
+//     tests and the material code each run with many lanes instead of every round executing all
+//     three for a few lanes each.
+//   * One memory round trip per body: a leaf's triangles are requested together, and the feed body
+//     requests the hit triangle, the first noise footprint and the sky footprint before it uses any.
+//   * Per-frame work is hoisted: the pixel jitter (a noise lookup that depends on the frame's seed
+//     only) is computed once per frame by prepare_frames_kernel; the material table sits in LDS.
 //   * Lanes are persistent over frames too: the running mean of a pixel stays in registers for all
 //     frames of a launch; the accumulation image is read and written once per launch.
 #include <hip/hip_runtime.h>
