@@ -98,34 +98,45 @@ __global__ __launch_bounds__(kBlurTX* kBlurTY) void blur_kernel(const float4* __
     tmp[(size_t)y * W + x] = make_float4(col[0] / d, col[1] / d, col[2] / d, 0.0f);
 }
 
-// GL_LINEAR up-blit of tmp[0:w,0:h] to the whole image; the filter footprint may reach one texel
-// beyond the corner (CLAMP_TO_EDGE acts at the texture edge, not at the source rectangle).
-__global__ void up_kernel(const float4* __restrict__ tmp, float4* __restrict__ level, int W, int H, int w, int h) {
+// Keeps what the GL_LINEAR up-blit of level i would read: tmp[0:w+1, 0:h+1], the corner plus the one texel of
+// bleed beyond it (CLAMP_TO_EDGE acts at the texture edge, not at the source rectangle, so that texel is whatever
+// earlier passes left in tmp). The next level overwrites the corner, hence the copy.
+__global__ void snap_kernel(const float4* __restrict__ tmp, float4* __restrict__ snap, int W, int sw, int sh) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= W || y >= H) return;
-    float u = ((float)x + 0.5f) * ((float)w / (float)W) - 0.5f;
-    float v = ((float)y + 0.5f) * ((float)h / (float)H) - 0.5f;
+    if (x >= sw || y >= sh) return;
+    snap[(size_t)y * sw + x] = tmp[(size_t)y * W + x];
+}
+
+struct LevelView { const float4* snap; int w, h, sw, sh; };
+
+// One pixel of the GL_LINEAR up-blit of a level's corner [0:w, 0:h] to the whole image, read from its snapshot.
+__device__ __forceinline__ float4 up_sample(const LevelView& L, int x, int y, int W, int H) {
+    float u = ((float)x + 0.5f) * ((float)L.w / (float)W) - 0.5f;
+    float v = ((float)y + 0.5f) * ((float)L.h / (float)H) - 0.5f;
     float fu = floorf(u), fv = floorf(v);
     float wx = u - fu, wy = v - fv;
     int x0 = (int)fu, y0 = (int)fv, x1 = x0 + 1, y1 = y0 + 1;
-    x0 = min(max(x0, 0), W - 1); x1 = min(max(x1, 0), W - 1); y0 = min(max(y0, 0), H - 1); y1 = min(max(y1, 0), H - 1);
-    float4 a = tmp[(size_t)y0 * W + x0], b = tmp[(size_t)y0 * W + x1], c = tmp[(size_t)y1 * W + x0], d = tmp[(size_t)y1 * W + x1];
+    // x1 <= w and y1 <= h always hold, so clamping to the snapshot equals clamping to the texture
+    x0 = min(max(x0, 0), L.sw - 1); x1 = min(max(x1, 0), L.sw - 1); y0 = min(max(y0, 0), L.sh - 1); y1 = min(max(y1, 0), L.sh - 1);
+    float4 a = L.snap[(size_t)y0 * L.sw + x0], b = L.snap[(size_t)y0 * L.sw + x1], c = L.snap[(size_t)y1 * L.sw + x0], d = L.snap[(size_t)y1 * L.sw + x1];
     float4 o;
     { float top = a.x + wx * (b.x - a.x), bot = c.x + wx * (d.x - c.x); o.x = top + wy * (bot - top); }
     { float top = a.y + wx * (b.y - a.y), bot = c.y + wx * (d.y - c.y); o.y = top + wy * (bot - top); }
     { float top = a.z + wx * (b.z - a.z), bot = c.z + wx * (d.z - c.z); o.z = top + wy * (bot - top); }
     o.w = 0.0f;
-    level[(size_t)y * W + x] = o;
+    return o;
 }
 
-// Fi:17-30
-__global__ void final_kernel(const float4* __restrict__ accum, const float4* __restrict__ l0, const float4* __restrict__ l1,
-                             const float4* __restrict__ l2, const float4* __restrict__ l3, float4* __restrict__ tmp, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// Fi:17-30, with the four up-blits of main.cpp:262-268 evaluated in place: the reference first writes each level,
+// enlarged to the whole window, into a texture of its own and reads the four back here; the values added are the same.
+__global__ void final_kernel(const float4* __restrict__ accum, LevelView l0, LevelView l1, LevelView l2, LevelView l3,
+                             float4* __restrict__ tmp, int W, int H) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const size_t i = (size_t)y * W + x;
     float4 s = accum[i];
     const float g = 1.0f / 1.61803f;
-    float4 a = l0[i], b = l1[i], c = l2[i], d = l3[i];
+    float4 a = up_sample(l0, x, y, W, H), b = up_sample(l1, x, y, W, H), c = up_sample(l2, x, y, W, H), d = up_sample(l3, x, y, W, H);
     float r = powf(s.x, g), gr = powf(s.y, g), bl = powf(s.z, g);
     r += a.x; r += b.x; r += c.x; r += d.x;
     gr += a.y; gr += b.y; gr += c.y; gr += d.y;
@@ -150,14 +161,15 @@ struct PostScratch {
     uint32_t W = 0, H = 0;
     float4* tmp = nullptr;            // persists between calls, like the reference's tmp texture
     float4* pre = nullptr;
-    float4* level[kLevels] = {nullptr, nullptr, nullptr, nullptr};
+    float4* snap[kLevels] = {nullptr, nullptr, nullptr, nullptr};   // per level: blurred corner + one texel of bleed
+    int sw[kLevels] = {0, 0, 0, 0}, sh[kLevels] = {0, 0, 0, 0};
     uint8_t* rgb8 = nullptr;
 };
 
 void Release(PostScratch* s) {
     if (s->tmp) (void)hipFree(s->tmp);
     if (s->pre) (void)hipFree(s->pre);
-    for (auto& l : s->level) if (l) (void)hipFree(l);
+    for (auto& l : s->snap) if (l) (void)hipFree(l);
     if (s->rgb8) (void)hipFree(s->rgb8);
     *s = PostScratch();
 }
@@ -210,7 +222,13 @@ int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint
         hipError_t e = hipMalloc((void**)&s->tmp, n * 16);
         if (e == hipSuccess) e = hipMemsetAsync(s->tmp, 0, n * 16, st);
         if (e == hipSuccess) e = hipMalloc((void**)&s->pre, n * 16);
-        for (int i = 0; i < kLevels && e == hipSuccess; ++i) e = hipMalloc((void**)&s->level[i], n * 16);
+        {
+            const int dsz[kLevels] = {5, 10, 20, 40};
+            for (int i = 0; i < kLevels && e == hipSuccess; ++i) {
+                s->sw[i] = min((int)width / dsz[i] + 1, (int)width); s->sh[i] = min((int)height / dsz[i] + 1, (int)height);
+                e = hipMalloc((void**)&s->snap[i], (size_t)s->sw[i] * s->sh[i] * 16);
+            }
+        }
         if (e == hipSuccess) e = hipMalloc((void**)&s->rgb8, n * 3);
         if (e != hipSuccess) { Release(s); err = hipGetErrorString(e); return RT_ERR_DEVICE; }
         s->W = width; s->H = height;
@@ -229,14 +247,16 @@ int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint
             const int pw = min(W, rw[i] + kApron), ph = min(H, rh[i] + kApron);
             hipLaunchKernelGGL(pre_kernel, grid2(pw, ph), b2, 0, st, s->tmp, s->pre, W, pw, ph);
             hipLaunchKernelGGL(blur_kernel, grid2(rw[i], rh[i]), dim3(kBlurTX, kBlurTY), 0, st, s->pre, s->tmp, W, H, pw, ph, rw[i], rh[i]);
-            hipLaunchKernelGGL(up_kernel, grid2(W, H), b2, 0, st, s->tmp, s->level[i], W, H, w, h);
+            hipLaunchKernelGGL(snap_kernel, grid2(s->sw[i], s->sh[i]), b2, 0, st, s->tmp, s->snap[i], W, s->sw[i], s->sh[i]);
         }
     }
     // bloom off = the raw blit of main.cpp:235-240: the accumulation is shown as it is and tmp is left alone
     const float4* shown = accum;
     if (bloomOn) {
-        hipLaunchKernelGGL(final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, accum, s->level[0], s->level[1], s->level[2],
-                           s->level[3], s->tmp, n);
+        const int dsz[kLevels] = {5, 10, 20, 40};
+        LevelView lv[kLevels];
+        for (int i = 0; i < kLevels; ++i) lv[i] = LevelView{s->snap[i], W / dsz[i], H / dsz[i], s->sw[i], s->sh[i]};
+        hipLaunchKernelGGL(final_kernel, grid2(W, H), b2, 0, st, accum, lv[0], lv[1], lv[2], lv[3], s->tmp, W, H);
         shown = s->tmp;
     }
     if (hipGetLastError() != hipSuccess) { err = "kernel launch failed"; return RT_ERR_DEVICE; }
