@@ -236,7 +236,7 @@ __device__ __forceinline__ void push(const StackRef& st, int& top, uint32_t ref,
 
 // Pops deferred nodes until one is still worth visiting (F:277-283 with the entry distance kept
 // from push time). Sets the lane's next state.
-template <bool COUNT>
+template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
     for (;;) {
         if (L.top == 0) { L.cur = kNoRef; L.state = kShade; return; }
@@ -246,7 +246,7 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
             unsigned long long w = st.spill[(uint32_t)(L.top - kLdsStack) * 64u + st.lane];
             e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
         }
-        L.iters++;
+        if (ITERS) L.iters++;
         if (__uint_as_float(e.y) >= L.bestT) continue;
         L.cur = e.x;
         L.state = (e.x & kLeafBit) ? kLeaf : kInterior;
@@ -255,13 +255,13 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
 }
 
 // Starts the traversal of L.ray: the root's own box test (the first pop of F:276-283).
-template <bool COUNT>
+template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, Tally& tl) {
     L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0; L.top = 0; L.cur = kNoRef;
     L.state = kShade;
     tl.rays++;
     if (sp.rootRef != kNoRef) {
-        L.iters = 1;
+        if (ITERS) L.iters = 1;
         float tr;
         if (COUNT) tl.boxes++;
         if (hit_box(L.ray, sp.rootMin[0], sp.rootMin[1], sp.rootMin[2], sp.rootMax[0], sp.rootMax[1], sp.rootMax[2], tr) && !(tr >= L.bestT)) {
@@ -273,7 +273,7 @@ __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, 
 
 // One interior node: both children from one 64-byte record, F:296-311. An interior reference is the
 // record's byte offset, so the address is the (scalar) array base plus a 32-bit lane offset.
-template <bool COUNT>
+template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void interior_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
     const float4* N = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sp.nodes) + L.cur);
     float4 n0 = N[0], n1 = N[1], n2 = N[2];
@@ -289,12 +289,12 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     const bool leftFirst = tL < tR;
     if (okL || okR) {
         if (okL && okR) push(st, L.top, leftFirst ? refR : refL, leftFirst ? tR : tL);
-        L.iters++;               // the immediate pop of the chosen child (its test passes: bestT is unchanged)
+        if (ITERS) L.iters++;    // the immediate pop of the chosen child (its test passes: bestT is unchanged)
         const bool takeLeft = okL && (leftFirst || !okR);
         L.cur = takeLeft ? refL : refR;
         L.state = (L.cur & kLeafBit) ? kLeaf : kInterior;
     } else {
-        pop_next<COUNT>(st, L);
+        pop_next<COUNT, ITERS>(st, L);
     }
 }
 
@@ -318,7 +318,7 @@ __device__ __forceinline__ bool hit_triangle(const Ray& r, float4 a, float4 b, f
 // triangles (the reference builds leaves of at most three) are requested together so that the
 // leaf costs one memory round trip; indices past the leaf's end are clamped to its last triangle
 // and their result ignored.
-template <bool COUNT>
+template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
     const uint32_t first = L.cur & 0x07ffffffu, count = ((L.cur >> 27) & 15u) + 1u;
     const uint32_t last = first + count - 1u;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef&
         const float4* T = reinterpret_cast<const float4*>(sp.tris + i);
         if (hit_triangle(L.ray, T[0], T[1], T[2].x, t) && L.bestT > t) { L.bestT = t; L.bestIdx = (int)i; }
     }
-    pop_next<COUNT>(st, L);
+    pop_next<COUNT, ITERS>(st, L);
 }
 
 // Fills in the per-frame pixel jitter (F:461: the noise lookup there depends on the frame's seed
@@ -353,8 +353,9 @@ __global__ void prepare_frames_kernel(SceneParams sp, FrameParams* __restrict__ 
 }
 
 // COUNT: full tallies; IDS: primary-hit ids instead of radiance (one frame); SINGLE: the launch
-// renders one frame, whose parameters then live in scalar registers.
-template <bool COUNT, bool IDS, bool SINGLE>
+// renders one frame, whose parameters then live in scalar registers; ITERS: the shader's iterationsCount is
+// kept (needed by the tallies, the id pass and the heat-map view of bounce limit 0 only).
+template <bool COUNT, bool IDS, bool SINGLE, bool ITERS>
 __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
                                                    float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
                                                    int32_t* __restrict__ ids /* IDS only: [slot][3] */,
@@ -424,15 +425,17 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
         if (nInt == most && !runFeed && !runLeaf) {
             // the hot loop: stay in it while most of the lanes that entered are still descending
             int steps = 0;
+            bool descending = L.state == kInterior;
             do {
-                if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += (L.state == kInterior); }
-                if (L.state == kInterior) interior_step<COUNT>(sp, st, L, tl);
+                if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += descending; }
+                if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
+                descending = L.state == kInterior;
                 ++steps;
-            } while (steps < RT_INT_STEPS && __popcll(__ballot(L.state == kInterior)) * RT_KEEP_DEN >= nInt * RT_KEEP_NUM);
+            } while (steps < RT_INT_STEPS && __popcll(__ballot(descending)) * RT_KEEP_DEN >= nInt * RT_KEEP_NUM);
             if (COUNT) rc.stop(1);
         } else if (runLeaf || (nLeaf == most && !runFeed)) {
             if (COUNT) { tl.rounds[2] += (lane == 0); tl.lanes[2] += (L.state == kLeaf); }
-            if (L.state == kLeaf) leaf_step<COUNT>(sp, st, L, tl);
+            if (L.state == kLeaf) leaf_step<COUNT, ITERS>(sp, st, L, tl);
             if (COUNT) rc.stop(2);
         } else {
             // ================= shading round: shade, hand out pixels, start paths =================
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                             ++L.segments;
                             // F:384,448; plus a bound on free glass bounces so that every wave is sure to finish
                             if (!((uint32_t)ii <= BL) || L.segments >= kMaxSegments) { result = mk(0.0f, 0.0f, 0.0f); done = true; }
-                            else begin_traversal<COUNT>(sp, L, tl);
+                            else begin_traversal<COUNT, ITERS>(sp, L, tl);
                         }
                     }
                 }
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                 L.throughput = mk(1.0f, 1.0f, 1.0f);
                 L.bounce = 0; L.segments = 0;
                 hitNormal = mk(0.0f, 0.0f, 0.0f);          // a new invocation starts with a blank hit record
-                begin_traversal<COUNT>(sp, L, tl);
+                begin_traversal<COUNT, ITERS>(sp, L, tl);
             }
             if (COUNT) rc.stop(3);
         }
@@ -699,7 +702,7 @@ uint32_t ResidentWaves() {
     int dev = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false, true>, 64, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false, true, false>, 64, 0) != hipSuccess) return 0;
     if (perCu < 1) perCu = 1;
     return (uint32_t)cus * (uint32_t)perCu;
 }
@@ -715,12 +718,15 @@ void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const Sc
     uint2* sa = static_cast<uint2*>(spillArea);
     dim3 grid(nWaves), block(64);
     const bool single = nFrames == 1u;
-#define RT_LAUNCH(C, I, S) hipLaunchKernelGGL((trace_kernel<C, I, S>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost)
-    if (ids) RT_LAUNCH(true, true, true);
-    else if (count && single) RT_LAUNCH(true, false, true);
-    else if (count) RT_LAUNCH(true, false, false);
-    else if (single) RT_LAUNCH(false, false, true);
-    else RT_LAUNCH(false, false, false);
+    const bool heat = sp.bounceLimit == 0u;        // the only view that shows iterationsCount
+#define RT_LAUNCH(C, I, S, T) hipLaunchKernelGGL((trace_kernel<C, I, S, T>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost)
+    if (ids) RT_LAUNCH(true, true, true, true);
+    else if (count && single) RT_LAUNCH(true, false, true, true);
+    else if (count) RT_LAUNCH(true, false, false, true);
+    else if (single && heat) RT_LAUNCH(false, false, true, true);
+    else if (single) RT_LAUNCH(false, false, true, false);
+    else if (heat) RT_LAUNCH(false, false, false, true);
+    else RT_LAUNCH(false, false, false, false);
 #undef RT_LAUNCH
 }
 
