@@ -164,7 +164,11 @@ __device__ __forceinline__ bool hit_box(const Ray& r, float mnx, float mny, floa
     float lo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
     float hi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
     tmin = lo;
-    return hi >= fmaxf(lo, 0.0f);
+    // max(lo, 0) as the one v_max_f32 it is: written as fmaxf the compiler first re-quiets `lo` with a second
+    // v_max_f32, which the three-operand maximum that produced it has already done.
+    float lo0;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(lo0) : "v"(lo));
+    return hi >= lo0;
 }
 
 
@@ -176,7 +180,11 @@ struct RoundClock {
     __device__ __forceinline__ void stop(int state) { cycles[state] += __builtin_readcyclecounter() - t0; }
 };
 
-enum LaneState : int { kIdle = 0, kNewPath = 1, kInterior = 2, kLeaf = 3, kShade = 4 };
+enum LaneState : int { kIdle = 0, kNewPath = 1, kTraverse = 2, kShade = 4 };
+// What a traversing lane stands on is read from its reference, Lane::cur: an interior record's byte offset (bit 31
+// clear, below kNoRef), a leaf (bit 31 set), or kNoRef for every lane that is not traversing.
+__device__ __forceinline__ bool at_interior(uint32_t cur) { return cur < kNoRef; }
+__device__ __forceinline__ bool at_leaf(uint32_t cur) { return (int32_t)cur < 0; }
 
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 14
@@ -249,7 +257,6 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
         if (ITERS) L.iters++;
         if (__uint_as_float(e.y) >= L.bestT) continue;
         L.cur = e.x;
-        L.state = (e.x & kLeafBit) ? kLeaf : kInterior;
         return;
     }
 }
@@ -266,7 +273,7 @@ __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, 
         if (COUNT) tl.boxes++;
         if (hit_box(L.ray, sp.rootMin[0], sp.rootMin[1], sp.rootMin[2], sp.rootMax[0], sp.rootMax[1], sp.rootMax[2], tr) && !(tr >= L.bestT)) {
             L.cur = sp.rootRef;
-            L.state = (sp.rootRef & kLeafBit) ? kLeaf : kInterior;
+            L.state = kTraverse;
         }
     }
 }
@@ -292,7 +299,6 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
         if (ITERS) L.iters++;    // the immediate pop of the chosen child (its test passes: bestT is unchanged)
         const bool takeLeft = okL && (leftFirst || !okR);
         L.cur = takeLeft ? refL : refR;
-        L.state = (L.cur & kLeafBit) ? kLeaf : kInterior;
     } else {
         pop_next<COUNT, ITERS>(st, L);
     }
@@ -413,8 +419,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
         // ---- pick what to run: the most populated of interior / leaf / feed (ballot + popcount, wave-uniform).
         // "Feed" is everything the shading round serves: lanes with a finished traversal, lanes about to start
         // a path, and idle lanes while pixels are left to hand out.
-        const int nInt = __popcll(__ballot(L.state == kInterior));
-        const int nLeaf = __popcll(__ballot(L.state == kLeaf));
+        const int nInt = __popcll(__ballot(at_interior(L.cur)));
+        const int nLeaf = __popcll(__ballot(at_leaf(L.cur)));
         const bool pixelsLeft = (poolNext != poolEnd) || !queueEmpty;
         const int nFeed = __popcll(__ballot(L.state == kShade || L.state == kNewPath || (pixelsLeft && L.state == kIdle)));
         if ((nInt | nLeaf | nFeed) == 0) break;      // every wave reaches this: the queues only shrink
@@ -425,17 +431,17 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
         if (nInt == most && !runFeed && !runLeaf) {
             // the hot loop: stay in it while most of the lanes that entered are still descending
             int steps = 0;
-            bool descending = L.state == kInterior;
+            bool descending = at_interior(L.cur);
             do {
                 if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += descending; }
                 if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
-                descending = L.state == kInterior;
+                descending = at_interior(L.cur);
                 ++steps;
             } while (steps < RT_INT_STEPS && __popcll(__ballot(descending)) * RT_KEEP_DEN >= nInt * RT_KEEP_NUM);
             if (COUNT) rc.stop(1);
         } else if (runLeaf || (nLeaf == most && !runFeed)) {
-            if (COUNT) { tl.rounds[2] += (lane == 0); tl.lanes[2] += (L.state == kLeaf); }
-            if (L.state == kLeaf) leaf_step<COUNT, ITERS>(sp, st, L, tl);
+            if (COUNT) { tl.rounds[2] += (lane == 0); tl.lanes[2] += at_leaf(L.cur); }
+            if (at_leaf(L.cur)) leaf_step<COUNT, ITERS>(sp, st, L, tl);
             if (COUNT) rc.stop(2);
         } else {
             // ================= shading round: shade, hand out pixels, start paths =================
