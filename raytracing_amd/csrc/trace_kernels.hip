@@ -207,6 +207,9 @@ __device__ __forceinline__ bool at_leaf(uint32_t cur) { return (int32_t)cur < 0;
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 5
 #endif
+#ifndef RT_DOUBLE_STEP
+#define RT_DOUBLE_STEP 1
+#endif
 constexpr int kLdsStack = RT_LDS_STACK;   // stack entries per lane kept in LDS (512 B per entry per wave)
 
 // Everything a lane carries between scheduler rounds.
@@ -437,6 +440,13 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                 if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
                 descending = at_interior(L.cur);
                 ++steps;
+#if RT_DOUBLE_STEP
+                // a second node visit before the wave re-counts its lanes: half the loop control per visit
+                if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += descending; }
+                if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
+                descending = at_interior(L.cur);
+                ++steps;
+#endif
             } while (steps < RT_INT_STEPS && __popcll(__ballot(descending)) * RT_KEEP_DEN >= nInt * RT_KEEP_NUM);
             if (COUNT) rc.stop(1);
         } else if (runLeaf || (nLeaf == most && !runFeed)) {
