@@ -157,3 +157,51 @@ def test_reupload_on_one_context_equals_fresh_context():
     r.render(0, SEEDS[:3])
     assert differing_pixels(r.read_accum(), want) == 0
     r.close()
+
+
+def _unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return tuple(np.float32(v / np.linalg.norm(v)))
+
+
+CAMERAS = [
+    # position, facing (unit), field of view in degrees
+    ((1.5, -0.8, 0.6), _unit((1.0, 0.7, -0.2)), 90.0),
+    ((4.0, 0.5, 1.2), _unit((-1.0, 0.1, 0.05)), 60.0),       # looking back towards the origin
+    ((0.0, 0.0, 2.5), _unit((0.3, 0.2, -1.0)), 140.0),       # steeply downwards, very wide
+]
+
+
+@pytest.mark.parametrize("cam", range(len(CAMERAS)))
+def test_moved_and_rotated_cameras_bit_exact(cam):
+    """Other poses and fields of view than the default one (Include/Camera.h:7-11), as Camera::UploadInfo sends them."""
+    import math
+    pos, facing, fov_deg = CAMERAS[cam]
+    fov = np.float32(fov_deg * 0.01745329251994329576923690768489)
+    camera = dict(position=pos, facing=facing, fov=float(fov), viewport_width=float(np.float32(2.0 * math.tan(float(fov) / 2.0))))
+    W, H = 120, 72
+    sc = make_scene("sponza_like", target_tris=20000)
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    for r in (g, o):
+        setup(r, sc, NOISE, SKY, camera=camera, bounce_limit=8)
+        r.render(0, SEEDS[:3])
+    a, b = g.read_accum(), o.read_accum()
+    assert np.isfinite(b[..., :3]).all()
+    assert differing_pixels(a, b) == 0
+    # the id pass last: the oracle's renders a frame into its accumulation image as a side effect, the product's does not
+    assert (g.primary_ids(SEEDS[0]) == o.primary_ids(SEEDS[0])).all()
+    assert differing_pixels(g.read_accum(), a) == 0
+    g.close()
+
+
+def test_bounce_limit_32_and_a_long_launch_bit_exact():
+    """The largest limit the reference's keys select (src/BounceLimitManager.cpp:14-48) and 40 frames in one launch."""
+    W, H = 64, 40
+    sc = make_scene("dragon_like", target_tris=12000)
+    seeds = scenes.frame_seeds(40)
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    for r in (g, o):
+        setup(r, sc, NOISE, SKY, bounce_limit=32)
+        r.render(0, seeds)
+    assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+    g.close()
