@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--workload", default="sponza_like_3840x2160_b8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented replay that measures algorithmic bytes")
+    ap.add_argument("--verify", action="store_true", help="N > 1: check the assembled image bit for bit against an unsharded render of the same frames")
     args = ap.parse_args()
 
     import torch
@@ -161,9 +162,13 @@ def main():
         if pending[b] is None:
             return
         if backend == "nccl":
-            pending[b].wait()
+            pending[b].wait()                    # torch's current stream now waits for the gather
         if rank == 0:
-            torch.cuda.synchronize()
+            # Wait for the gather only (it was started a frame ago), not for the whole device: the frame being
+            # traced on the renderer's own stream keeps running while the previous one is assembled.
+            done = torch.cuda.Event()
+            done.record()
+            done.synchronize()
             root.assemble(flats[b].data_ptr(), world)
         pending[b] = None
 
@@ -175,6 +180,8 @@ def main():
         r.export_shard(stage[b].data_ptr())      # queued behind the frame on the renderer's stream
         finish(k - 1)                            # the previous frame's exchange overlapped with this frame's tracing
         r.sync()
+        if root is not None:
+            root.sync()                          # the receive buffer of this parity was read by the assembly of frame k-2
         if backend == "nccl":
             pending[b] = dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
         else:
@@ -207,6 +214,18 @@ def main():
         step(k)
     fence()
     dt = time.perf_counter() - t0
+
+    if args.verify and world > 1 and rank == 0:
+        whole = ra.Renderer(W, H, device=device)
+        setup(whole, sc, noise, sky, bl)
+        for k in range(Wm + K):
+            whole.render(k, seeds[k:k + 1])
+        a, b = root.read_accum(), whole.read_accum()
+        same = bool((a.view(np.uint32) == b.view(np.uint32)).all())
+        print("verify: image assembled from %d shards %s the unsharded render" % (world, "equals" if same else "DIFFERS FROM"), file=sys.stderr)
+        whole.close()
+        if not same:
+            raise SystemExit("sharded and unsharded images differ")
 
     c = r.counters(reset=True)
     kms, launches = r.kernel_time(reset=True)
