@@ -61,8 +61,9 @@ def load_workload(name, threads):
             q = os.path.join(cache, os.path.basename(p))
             os.replace(p, q)
             final.append(q)
-        with open(paths_file, "w") as f:
+        with open(paths_file + ".tmp%d" % os.getpid(), "w") as f:
             json.dump(final, f)
+        os.replace(f.name, paths_file)       # atomically: another process may be looking for it right now
     with open(paths_file) as f:
         paths = json.load(f)
     return ra.load_scene(paths, build_threads=threads), W, H, bl
@@ -129,14 +130,23 @@ def main():
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     device = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 runs the exchange path (gather, assembly, reductions) even with a single rank, so that a
+    # one-GPU box can rehearse it with the real backend: python -m torch.distributed.run --nproc-per-node 1 bench.py
+    sharded = world > 1 or (os.environ.get("RT_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if sharded:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
 
     K, Wm = args.steps, args.warmup
+    # The first use of a workload writes its scene files to a cache directory: rank 0 goes first, the others then
+    # find the cache complete.
+    if sharded and rank != 0:
+        dist.barrier()
     sc, W, H, bl = load_workload(args.workload, threads=min(16, os.cpu_count() or 1))
+    if sharded and rank == 0:
+        dist.barrier()
     noise, sky = scenes.noise_texture(), scenes.sky_cubemap()
     seeds = scenes.frame_seeds(Wm + K)
 
@@ -145,7 +155,7 @@ def main():
     root = None
     stage = flats = gathered = None
     pending = [None, None]
-    if world > 1:
+    if sharded:
         r.set_shard(rank, world)
         n = r.shard_tiles() * 64 * 4
         # torch tensors are only plumbing: device memory for the gather's send and receive sides.
@@ -162,19 +172,21 @@ def main():
         if pending[b] is None:
             return
         if backend == "nccl":
-            pending[b].wait()                    # torch's current stream now waits for the gather
-        if rank == 0:
-            # Wait for the gather only (it was started a frame ago), not for the whole device: the frame being
-            # traced on the renderer's own stream keeps running while the previous one is assembled.
+            # wait() only makes torch's current stream wait for the gather; the host has to know that it is over,
+            # on every rank: the send buffer of this parity is written again by the renderer's own stream two frames
+            # on, and rank 0 reads the received shards on yet another stream. Waiting for the gather alone (it was
+            # started a frame ago) instead of the whole device lets the frame being traced keep running.
+            pending[b].wait()
             done = torch.cuda.Event()
             done.record()
             done.synchronize()
+        if rank == 0:
             root.assemble(flats[b].data_ptr(), world)
         pending[b] = None
 
     def step(k):
         r.render(k, seeds[k:k + 1])
-        if world == 1:
+        if not sharded:
             return
         b = k & 1
         r.export_shard(stage[b].data_ptr())      # queued behind the frame on the renderer's stream
@@ -199,13 +211,13 @@ def main():
         if root is not None:
             root.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
 
     for k in range(Wm):
         step(k)
     fence()
-    saved = r.read_accum() if (world == 1 and not args.no_roofline_pass) else None
+    saved = r.read_accum() if (not sharded and not args.no_roofline_pass) else None
     r.counters(reset=True)
     r.kernel_time(reset=True)
     fence()
@@ -215,7 +227,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    if args.verify and world > 1 and rank == 0:
+    if args.verify and sharded and rank == 0:
         whole = ra.Renderer(W, H, device=device)
         setup(whole, sc, noise, sky, bl)
         for k in range(Wm + K):
@@ -230,7 +242,7 @@ def main():
     c = r.counters(reset=True)
     kms, launches = r.kernel_time(reset=True)
     stats = torch.tensor([dt, float(c["rays"]), float(c["paths"]), kms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
+    if sharded:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone()
@@ -240,7 +252,7 @@ def main():
         rays, paths, kms_max = float(c["rays"]), float(c["paths"]), kms
 
     roofline = None
-    if world == 1 and not args.no_roofline_pass:
+    if not sharded and not args.no_roofline_pass:
         # instrumented replay of exactly the timed frames from the same accumulation state
         r.write_accum(saved)
         r.set_counting(True)
@@ -282,16 +294,16 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "scene_triangles": sc.n_triangles, "bvh_nodes": sc.n_nodes,
                        "resolution": [W, H], "bounce_limit": bl, "spp_per_step": 1,
-                       "parallelism": "tiles%d" % world if world > 1 else "single",
+                       "parallelism": "tiles%d" % world if sharded else "single",
                        "rays_per_step": round(rays / K), "mpaths_per_s": round(paths / dt / 1e6, 2),
                        "trace_kernel_ms_per_step": round(kms_max / K, 4)},
         }
         if roofline:
             out["roofline"] = roofline
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(sc, noise, sky, bl, W, H)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
