@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised check of the bloom chain + final composite: GPU (through the C ABI) against the CPU oracle.
-  python3 tools/fuzz_post.py [cases] [seed]
+  python3 tests/fuzz_post.py [cases] [seed]
 Random image sizes (from a few pixels to about 700x400), several consecutive calls per context so that the content
 the chain leaves in its work image is carried over, bloom on and off mixed. Tolerance 2e-5 absolute on the float image
 (two different powf implementations), one code on the 8-bit image. Test infrastructure: the oracle is only the checker."""
