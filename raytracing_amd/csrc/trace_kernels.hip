@@ -180,11 +180,13 @@ struct RoundClock {
     __device__ __forceinline__ void stop(int state) { cycles[state] += __builtin_readcyclecounter() - t0; }
 };
 
-enum LaneState : int { kIdle = 0, kNewPath = 1, kTraverse = 2, kShade = 4 };
+enum LaneState : int { kIdle = 0, kNewPath = 1, kTraverse = 2 };
 // What a traversing lane stands on is read from its reference, Lane::cur: an interior record's byte offset (bit 31
-// clear, below kNoRef), a leaf (bit 31 set), or kNoRef for every lane that is not traversing.
+// clear, below kNoRef), a leaf (bit 31 set), or kNoRef once the traversal is over and the lane waits to be shaded.
+// Lanes in the other two states carry kNoRef as well. The traversal code therefore never writes Lane::state.
 __device__ __forceinline__ bool at_interior(uint32_t cur) { return cur < kNoRef; }
 __device__ __forceinline__ bool at_leaf(uint32_t cur) { return (int32_t)cur < 0; }
+__device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return state == kTraverse && cur == kNoRef; }
 
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 14
@@ -209,6 +211,9 @@ __device__ __forceinline__ bool at_leaf(uint32_t cur) { return (int32_t)cur < 0;
 #endif
 #ifndef RT_DOUBLE_STEP
 #define RT_DOUBLE_STEP 1
+#endif
+#ifndef RT_SENTINEL
+#define RT_SENTINEL 1      // stack entry 0 of every lane is a stopper, so the pop loop has no "stack empty" case
 #endif
 constexpr int kLdsStack = RT_LDS_STACK;   // stack entries per lane kept in LDS (512 B per entry per wave)
 
@@ -246,11 +251,29 @@ __device__ __forceinline__ void push(const StackRef& st, int& top, uint32_t ref,
 }
 
 // Pops deferred nodes until one is still worth visiting (F:277-283 with the entry distance kept
-// from push time). Sets the lane's next state.
+// from push time). Leaves the next reference, or kNoRef when the traversal is over, in L.cur.
+//
+// The bottom entry of every lane's stack is a stopper, written once per launch: reference kNoRef with entry
+// distance -inf, which no `>= bestT` test skips. Popping it ends the traversal, so the loop needs no test for an
+// empty stack; a traversal starts with top = 1.
 template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
+#if RT_SENTINEL
     for (;;) {
-        if (L.top == 0) { L.cur = kNoRef; L.state = kShade; return; }
+        --L.top;
+        uint2 e = st.lds[min(L.top, kLdsStack - 1) * 64];
+        if (L.top >= kLdsStack) {
+            unsigned long long w = st.spill[(uint32_t)(L.top - kLdsStack) * 64u + st.lane];
+            e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+        }
+        if (ITERS) L.iters += (e.x != kNoRef);      // the stopper is not one of the shader's pops
+        if (__uint_as_float(e.y) >= L.bestT) continue;
+        L.cur = e.x;
+        break;
+    }
+#else
+    for (;;) {
+        if (L.top == 0) { L.cur = kNoRef; return; }
         --L.top;
         uint2 e = st.lds[min(L.top, kLdsStack - 1) * 64];
         if (L.top >= kLdsStack) {
@@ -262,22 +285,21 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
         L.cur = e.x;
         return;
     }
+#endif
 }
 
 // Starts the traversal of L.ray: the root's own box test (the first pop of F:276-283).
 template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, Tally& tl) {
-    L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0; L.top = 0; L.cur = kNoRef;
-    L.state = kShade;
+    L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0; L.top = RT_SENTINEL ? 1 : 0; L.cur = kNoRef;
+    L.state = kTraverse;
     tl.rays++;
     if (sp.rootRef != kNoRef) {
         if (ITERS) L.iters = 1;
         float tr;
         if (COUNT) tl.boxes++;
-        if (hit_box(L.ray, sp.rootMin[0], sp.rootMin[1], sp.rootMin[2], sp.rootMax[0], sp.rootMax[1], sp.rootMax[2], tr) && !(tr >= L.bestT)) {
+        if (hit_box(L.ray, sp.rootMin[0], sp.rootMin[1], sp.rootMin[2], sp.rootMax[0], sp.rootMax[1], sp.rootMax[2], tr) && !(tr >= L.bestT))
             L.cur = sp.rootRef;
-            L.state = kTraverse;
-        }
     }
 }
 
@@ -380,6 +402,9 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
     st.lds = lds_stack + lane;
     st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64;
     st.lane = lane;
+#if RT_SENTINEL
+    st.lds[0] = make_uint2(kNoRef, __float_as_uint(-INFINITY));      // the stopper below every traversal's entries
+#endif
 
     // the material table is small and read at every hit: keep a copy in LDS
     for (uint32_t j = lane; j < (uint32_t)(sizeof(MaterialRec) / 4 * kMaxMaterials); j += 64u)
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
         const int nInt = __popcll(__ballot(at_interior(L.cur)));
         const int nLeaf = __popcll(__ballot(at_leaf(L.cur)));
         const bool pixelsLeft = (poolNext != poolEnd) || !queueEmpty;
-        const int nFeed = __popcll(__ballot(L.state == kShade || L.state == kNewPath || (pixelsLeft && L.state == kIdle)));
+        const int nFeed = __popcll(__ballot(L.cur == kNoRef && (pixelsLeft || L.state != kIdle)));
         if ((nInt | nLeaf | nFeed) == 0) break;      // every wave reaches this: the queues only shrink
         const int most = max(nInt, max(nLeaf, nFeed));
         const bool runFeed = nFeed >= RT_SHADE_AT, runLeaf = !runFeed && nLeaf >= RT_LEAF_AT;
@@ -455,8 +480,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
             if (COUNT) rc.stop(2);
         } else {
             // ================= shading round: shade, hand out pixels, start paths =================
-            if (COUNT) { tl.rounds[3] += (lane == 0); tl.lanes[3] += (L.state == kShade); }
-            if (L.state == kShade) {
+            if (COUNT) { tl.rounds[3] += (lane == 0); tl.lanes[3] += awaits_shading(L.state, L.cur); }
+            if (awaits_shading(L.state, L.cur)) {
                 if (COUNT) tl.pops += (uint32_t)L.iters;
                 const bool hitAnything = L.bestIdx >= 0;
                 bool done = false;          // path finished with colour `result`
