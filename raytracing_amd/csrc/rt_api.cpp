@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -306,6 +307,18 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
     return RT_OK;
 }
 
+namespace {
+constexpr float kAirIndex = 1.0003f;     // Fragment.glsl:329
+
+// a / b as the kernels compute it: correctly rounded fp32 with denormal operands read as zero and a denormal
+// result flushed to zero (the host's division rounds the same way; only the flushing has to be added).
+float DeviceQuotient(float a, float b) {
+    auto flush = [](float v) { return std::fabs(v) < FLT_MIN ? std::copysign(0.0f, v) : v; };
+    volatile float q = flush(a) / flush(b);
+    return flush(q);
+}
+}  // namespace
+
 int rt_set_materials(rt_context* c, const rt_material* m, uint32_t count) {
     if (!c) return RT_ERR_INVALID;
     if (count > (uint32_t)kMaxMaterials) return Fail(c, RT_ERR_UNSUPPORTED, "rt_set_materials: %u materials (limit 16)", count);
@@ -316,7 +329,9 @@ int rt_set_materials(rt_context* c, const rt_material* m, uint32_t count) {
     for (uint32_t i = 0; i < count; ++i) {
         for (int k = 0; k < 3; ++k) { recs[i].colour[k] = m[i].colour[k]; recs[i].specular[k] = m[i].specularColour[k]; }
         recs[i].roughness = m[i].roughness; recs[i].metallic = m[i].metallic; recs[i].transparency = m[i].transparency;
-        recs[i].refractionIndex = m[i].refractionIndex; recs[i].isLight = m[i].isLight ? 1 : 0;
+        recs[i].airOverIndex = DeviceQuotient(kAirIndex, m[i].refractionIndex);
+        recs[i].indexOverAir = DeviceQuotient(m[i].refractionIndex, kAirIndex);
+        recs[i].isLight = m[i].isLight ? 1 : 0;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->dMaterials, recs, sizeof recs, hipMemcpyHostToDevice));

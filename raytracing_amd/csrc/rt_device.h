@@ -56,10 +56,12 @@ static_assert(sizeof(TriRec) == 48, "triangle record must be 48 bytes");
 struct alignas(16) MaterialRec {   // Fragment.glsl:15-23
     float colour[3];
     float specular[3];
-    float roughness, metallic, transparency, refractionIndex;
+    float roughness, metallic, transparency;
+    float airOverIndex;          // 1.0003 / refractionIndex: what Fragment.glsl:330 divides per hit, divided once at upload
     int32_t isLight;
-    int32_t pad;
+    float indexOverAir;          // refractionIndex / 1.0003
 };
+static_assert(sizeof(MaterialRec) == 48, "material record must be 48 bytes");
 
 // Everything the tracer reads besides the big arrays; passed by value as a kernel argument
 // (lands in SGPRs / the kernarg segment, i.e. the scalar cache, like GL uniforms).

@@ -53,7 +53,45 @@ __device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // GLSL built-ins as llvmpipe lowers them
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
 __device__ __forceinline__ V3 cross3(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-__device__ __forceinline__ V3 normalize3(V3 v) { float r = 1.0f / sqrtf(dot3(v, v)); return v * r; }
+
+// ---- correctly rounded fp32 quotients in fewer instructions than the compiler's general sequence ----
+// The compiler expands every a / b into v_div_scale x2, v_rcp, five FMAs, v_div_fmas, v_div_fixup and a pair of
+// s_setreg that switch denormals on and off around them: about 13 instructions, because it must be right for every
+// pair (a, b). The two special cases below need less and return the same bits (tools/microbench/exact_math.hip
+// compares each with the compiler's division over all 2^32 inputs on the GPU).
+#ifndef RT_SHORT_DIV
+#define RT_SHORT_DIV 1
+#endif
+// 1 / x: hardware estimate (1 ulp), one Newton step in FMA, v_div_fixup for zeros, infinities and NaNs.
+// Equal to 1.0f / x for every one of the 2^32 inputs (denormals flushed, as in the rest of this file).
+__device__ __forceinline__ float rcp_exact(float x) {
+#if RT_SHORT_DIV
+    float y = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    return __builtin_amdgcn_div_fixupf(y, x, 1.0f);
+#else
+    return 1.0f / x;
+#endif
+}
+// a / c where c is the same in every lane and rc = 1.0f / c was computed once: product, then two residual
+// corrections in FMA (the second one rounds correctly by Markstein's theorem once the first has made the
+// quotient faithful; c's significand must not be all ones, true of the integers below 2^24 used here).
+// Equal to a / c for a = 0 and for 2^-100 <= |a| < inf: outside that range the residual underflows. The
+// numerators here are sums of integers and k/255 fractions, hence zero or at least 1/255 in magnitude.
+__device__ __forceinline__ float div_by_uniform(float a, float c, float rc) {
+#if RT_SHORT_DIV
+    float q = a * rc;
+    float r = __builtin_fmaf(-c, q, a);
+    q = __builtin_fmaf(r, rc, q);
+    r = __builtin_fmaf(-c, q, a);
+    return __builtin_fmaf(r, rc, q);
+#else
+    return a / c;
+#endif
+}
+
+__device__ __forceinline__ V3 normalize3(V3 v) { float r = rcp_exact(sqrtf(dot3(v, v))); return v * r; }
 __device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) { return a + t * (b - a); }
 __device__ __forceinline__ V3 reflect3(V3 I, V3 N) { float d = dot3(N, I); return I - (2.0f * d) * N; }
 __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
@@ -136,7 +174,7 @@ __device__ __forceinline__ Texels fetch_sky(const SceneParams& sp, V3 dir) {
     if (axis == 0) { sc = neg ? d.z : -d.z; tc = -d.y; }
     else if (axis == 1) { sc = d.x; tc = neg ? -d.z : d.z; }
     else { sc = neg ? -d.x : d.x; tc = -d.y; }
-    float ima = 0.5f / fabsf(ma);
+    float ima = 0.5f * rcp_exact(fabsf(ma));      // = 0.5f / |ma| bit for bit: the halving is exact
     float s = sc * ima + 0.5f, t = tc * ima + 0.5f;
     int x0, x1, y0, y1;
     Texels q;
@@ -154,7 +192,7 @@ __device__ __forceinline__ V3 uni3(V3 v) { return mk(uni(v.x), uni(v.y), uni(v.z
 
 struct Ray { V3 o, d, inv; };
 __device__ __forceinline__ Ray MakeRay(V3 o, V3 d) {            // F:135-142 (magnitude is always 1)
-    Ray r; r.o = o; r.d = d; r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); return r;
+    Ray r; r.o = o; r.d = d; r.inv = mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z)); return r;
 }
 
 // F:242-263. Returns hit flag, entry distance in tmin.
@@ -212,6 +250,9 @@ __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return
 #ifndef RT_DOUBLE_STEP
 #define RT_DOUBLE_STEP 1
 #endif
+#ifndef RT_COLD_SPILL
+#define RT_COLD_SPILL 1
+#endif
 #ifndef RT_SENTINEL
 #define RT_SENTINEL 1      // stack entry 0 of every lane is a stopper, so the pop loop has no "stack empty" case
 #endif
@@ -263,7 +304,13 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
         --L.top;
         uint2 e = st.lds[min(L.top, kLdsStack - 1) * 64];
         if (L.top >= kLdsStack) {
-            unsigned long long w = st.spill[(uint32_t)(L.top - kLdsStack) * 64u + st.lane];
+            // (the empty asm keeps the address arithmetic of this rare case inside the branch: without it the
+            // compiler maintains the spill index in the loop for every pop)
+            uint32_t deep = (uint32_t)(L.top - kLdsStack);
+#if RT_COLD_SPILL
+            asm volatile("" : "+v"(deep));
+#endif
+            unsigned long long w = st.spill[deep * 64u + st.lane];
             e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
         }
         if (ITERS) L.iters += (e.x != kNoRef);      // the stopper is not one of the shader's pops
@@ -335,7 +382,7 @@ __device__ __forceinline__ bool hit_triangle(const Ray& r, float4 a, float4 b, f
     V3 v0 = mk(a.x, a.y, a.z), e1 = mk(a.w, b.x, b.y), e2 = mk(b.z, b.w, e2z);
     V3 h = cross3(r.d, e2);
     float det = dot3(e1, h);
-    float invDet = 1.0f / det;
+    float invDet = rcp_exact(det);
     V3 s = r.o - v0;
     float u = invDet * dot3(s, h);
     V3 q = cross3(s, e1);
@@ -418,6 +465,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
     const V3 facing = mk(sp.camFacing[0], sp.camFacing[1], sp.camFacing[2]);
     const float resx = uni((float)sp.width), resy = uni((float)sp.height);
     const float nresx = uni((float)sp.noiseW), nresy = uni((float)sp.noiseH);
+    const float rresx = uni(1.0f / resx), rresy = uni(1.0f / resy), rnresx = uni(1.0f / nresx), rnresy = uni(1.0f / nresy);
     const float vpH = uni(sp.vpW * (resy / resx));                              // F:145
     const V3 U = uni3(normalize3(cross3(facing, mk(0.0f, 0.0f, 1.0f))));        // F:147
     const V3 Vd = uni3(normalize3(cross3(U, facing)));                          // F:148
@@ -521,8 +569,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                     uint32_t sx = Hashf(L.ray.o.x + L.ray.d.y) + Hash((uint32_t)i) + fp.hashX;
                     uint32_t sy = Hashf(L.ray.o.y + L.ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
                     float fsx = (float)sx, fsy = (float)sy;
-                    float seedx = (fsx - nresx * floorf(fsx / nresx)) / nresx;
-                    float seedy = (fsy - nresy * floorf(fsy / nresy)) / nresy;
+                    float seedx = div_by_uniform(fsx - nresx * floorf(div_by_uniform(fsx, nresx, rnresx)), nresx, rnresx);
+                    float seedy = div_by_uniform(fsy - nresy * floorf(div_by_uniform(fsy, nresy, rnresy)), nresy, rnresy);
                     // What every lane of the round reads first is requested here, before any of it is used:
                     // the hit triangle and the first noise footprint, or the sky footprint, share one memory
                     // round trip. All lanes take part in both groups of requests (a lane that missed reads
@@ -560,7 +608,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                             if (trRng < m.transparency) {
                                 // TransparentScatter, F:328-336
                                 const float AIR = 1.0003f;
-                                float ri = frontFace ? AIR / m.refractionIndex : m.refractionIndex / AIR;
+                                float ri = frontFace ? m.airOverIndex : m.indexOverAir;      // AIR / n : n / AIR
                                 float cos_theta = fminf(dot3(-L.ray.d, hitNormal), 1.0f);
                                 float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
                                 next = (ri * sin_theta <= 1.0f) ? refract3(L.ray.d, hitNormal, ri) : reflect3(L.ray.d, hitNormal);
@@ -662,8 +710,8 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                 const float fx = (float)((tile % sp.tilesX) * kTile + (inTile & 7u)) + 0.5f;
                 const float fy = (float)((tile / sp.tilesX) * kTile + (inTile >> 3)) + 0.5f;
                 if (COUNT) tl.noise++;
-                V3 pt = ((camPos + sp.vpD * facing) + (sp.vpW * (-0.5f + ((fx - 0.5f) + jx) / resx)) * U) +
-                        (vpH * (-0.5f + ((fy - 0.5f) + jy) / resy)) * Vd;
+                V3 pt = ((camPos + sp.vpD * facing) + (sp.vpW * (-0.5f + div_by_uniform((fx - 0.5f) + jx, resx, rresx))) * U) +
+                        (vpH * (-0.5f + div_by_uniform((fy - 0.5f) + jy, resy, rresy))) * Vd;
                 L.ray = MakeRay(camPos, normalize3(pt - camPos));
                 L.throughput = mk(1.0f, 1.0f, 1.0f);
                 L.bounce = 0; L.segments = 0;

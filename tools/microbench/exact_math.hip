@@ -1,0 +1,106 @@
+// Exhaustive comparison, over all 2^32 float bit patterns, of short instruction sequences against the
+// compiler's correctly rounded fp32 division / square root (same flags as the product: denormals flushed).
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fgpu-flush-denormals-to-zero tools/microbench/exact_math.hip -o tools/microbench/exact_math
+// Prints, per candidate, the number of inputs whose result differs in any bit (NaN results compare equal to NaN).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+__device__ __forceinline__ float rcp_fast(float x) {
+    float y = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    return __builtin_amdgcn_div_fixupf(y, x, 1.0f);
+}
+
+__device__ __forceinline__ float sqrt_fast(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r;
+    float h = 0.5f * r;
+    float e = __builtin_fmaf(-s, s, x);
+    float s1 = __builtin_fmaf(e, h, s);
+    // x = 0, inf, negative, NaN: the hardware estimate is already the answer (or NaN)
+    return (x == 0.0f || x == INFINITY) ? x : s1;
+}
+
+// a / c for a launch constant c with rc = RN(1/c): product, then two residual corrections
+__device__ __forceinline__ float div_const(float a, float c, float rc) {
+    float q = a * rc;
+    float r = __builtin_fmaf(-c, q, a);
+    q = __builtin_fmaf(r, rc, q);
+    r = __builtin_fmaf(-c, q, a);
+    return __builtin_fmaf(r, rc, q);
+}
+
+__device__ __forceinline__ bool same(float a, float b) {
+    return (__float_as_uint(a) == __float_as_uint(b)) || (a != a && b != b);
+}
+
+struct Report { unsigned long long bad; uint32_t first[8]; unsigned int byExp[512]; };
+
+__device__ void note(Report* rep, uint32_t bits) {
+    unsigned long long k = atomicAdd(&rep->bad, 1ull);
+    if (k < 8) rep->first[k] = bits;
+    atomicAdd(&rep->byExp[bits >> 23], 1u);       // sign and exponent of the input
+}
+
+// mode 0: 1/x   1: sqrt(x)   2: 1/sqrt(x) as two roundings   3: x / c   4: 0.5/x
+__global__ void check(int mode, float c, float rc, Report* rep) {
+    const uint64_t n = 1ull << 32, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float x = __uint_as_float((uint32_t)i);
+        float ref, got;
+        if (mode == 0) { ref = 1.0f / x; got = rcp_fast(x); }
+        else if (mode == 1) { ref = sqrtf(x); got = sqrt_fast(x); }
+        else if (mode == 2) { ref = 1.0f / sqrtf(x); got = rcp_fast(sqrt_fast(x)); }
+        else if (mode == 4) { ref = 0.5f / x; got = 0.5f * rcp_fast(x); }
+        else { ref = x / c; got = div_const(x, c, rc); }
+        if (!same(ref, got)) note(rep, (uint32_t)i);
+    }
+}
+
+// prints the runs of input exponents (sign, biased exponent) that hold mismatches
+static void ranges(const Report& h) {
+    for (int sgn = 0; sgn < 2; ++sgn) {
+        int e = 0;
+        while (e < 256) {
+            if (!h.byExp[sgn * 256 + e]) { ++e; continue; }
+            int e0 = e; unsigned long long n = 0;
+            while (e < 256 && h.byExp[sgn * 256 + e]) { n += h.byExp[sgn * 256 + e]; ++e; }
+            printf("      %c exponent %d..%d: %llu\n", sgn ? '-' : '+', e0, e - 1, n);
+        }
+    }
+}
+
+int main() {
+    Report* d; Report h;
+    if (hipMalloc(&d, sizeof(Report)) != hipSuccess) { printf("no device\n"); return 1; }
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    const char* names[5] = {"1/x", "sqrt(x)", "1/sqrt(x)", "", "0.5/x"};
+    for (int mode = 0; mode < 5; ++mode) {
+        if (mode == 3) continue;
+        hipMemset(d, 0, sizeof(Report));
+        hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, mode, 1.0f, 1.0f, d);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
+        hipMemcpy(&h, d, sizeof(Report), hipMemcpyDeviceToHost);
+        printf("%-10s differing inputs: %llu", names[mode], h.bad);
+        for (unsigned k = 0; k < 8 && k < h.bad; ++k) printf(" %08x", h.first[k]);
+        printf("\n");
+        ranges(h);
+    }
+    const float cs[] = {600.f, 400.f, 3840.f, 2160.f, 1920.f, 1080.f, 640.f, 360.f, 1280.f, 720.f, 64.f, 48.f, 37.f, 23.f, 1.f, 3.f, 7.f, 1000.f, 4096.f, 32768.f, 12345.f, 999.f};
+    for (float c : cs) {
+        hipMemset(d, 0, sizeof(Report));
+        hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, 3, c, 1.0f / c, d);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
+        hipMemcpy(&h, d, sizeof(Report), hipMemcpyDeviceToHost);
+        printf("x/%-8g differing inputs: %llu", c, h.bad);
+        for (unsigned k = 0; k < 8 && k < h.bad; ++k) printf(" %08x", h.first[k]);
+        printf("\n");
+        ranges(h);
+    }
+    hipFree(d);
+    return 0;
+}
