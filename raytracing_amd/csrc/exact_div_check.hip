@@ -1,37 +1,29 @@
-// Exhaustive comparison, over all 2^32 float bit patterns, of short instruction sequences against the
-// compiler's correctly rounded fp32 division / square root (same flags as the product: denormals flushed).
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fgpu-flush-denormals-to-zero tools/microbench/exact_math.hip -o tools/microbench/exact_math
-// Prints, per candidate, the number of inputs whose result differs in any bit (NaN results compare equal to NaN).
+// Exhaustive comparison, over all 2^32 float bit patterns, of the short quotient sequences of exact_div.h with the
+// compiler's correctly rounded fp32 division (same flags as the kernels: denormals flushed, no contraction).
+// Built by the Makefile into ../exact_div_check; tests/test_gpu_exact_div.py runs it and reads the report:
+// per candidate the number of inputs whose result differs in any bit (NaN results compare equal to NaN), and the
+// runs of input exponents (sign, biased exponent) that hold the differences.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
-__device__ __forceinline__ float rcp_fast(float x) {
-    float y = __builtin_amdgcn_rcpf(x);
-    float e = __builtin_fmaf(-x, y, 1.0f);
-    y = __builtin_fmaf(e, y, y);
-    return __builtin_amdgcn_div_fixupf(y, x, 1.0f);
-}
+#include "exact_div.h"
 
-__device__ __forceinline__ float sqrt_fast(float x) {
+using namespace rtd;
+#if !RT_SHORT_DIV
+#error "the checker compares the short sequences with the plain operators: build it with RT_SHORT_DIV=1"
+#endif
+
+// A candidate that is NOT used by the kernels, kept to show why: a short square root is exact only for x >= 2^-102.
+__device__ __forceinline__ float sqrt_short(float x) {
     float r = __builtin_amdgcn_rsqf(x);
     float s = x * r;
     float h = 0.5f * r;
     float e = __builtin_fmaf(-s, s, x);
     float s1 = __builtin_fmaf(e, h, s);
-    // x = 0, inf, negative, NaN: the hardware estimate is already the answer (or NaN)
     return (x == 0.0f || x == INFINITY) ? x : s1;
-}
-
-// a / c for a launch constant c with rc = RN(1/c): product, then two residual corrections
-__device__ __forceinline__ float div_const(float a, float c, float rc) {
-    float q = a * rc;
-    float r = __builtin_fmaf(-c, q, a);
-    q = __builtin_fmaf(r, rc, q);
-    r = __builtin_fmaf(-c, q, a);
-    return __builtin_fmaf(r, rc, q);
 }
 
 __device__ __forceinline__ bool same(float a, float b) {
@@ -52,11 +44,11 @@ __global__ void check(int mode, float c, float rc, Report* rep) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float x = __uint_as_float((uint32_t)i);
         float ref, got;
-        if (mode == 0) { ref = 1.0f / x; got = rcp_fast(x); }
-        else if (mode == 1) { ref = sqrtf(x); got = sqrt_fast(x); }
-        else if (mode == 2) { ref = 1.0f / sqrtf(x); got = rcp_fast(sqrt_fast(x)); }
-        else if (mode == 4) { ref = 0.5f / x; got = 0.5f * rcp_fast(x); }
-        else { ref = x / c; got = div_const(x, c, rc); }
+        if (mode == 0) { ref = 1.0f / x; got = rcp_exact(x); }
+        else if (mode == 1) { ref = sqrtf(x); got = sqrt_short(x); }
+        else if (mode == 2) { ref = 1.0f / sqrtf(x); got = rcp_exact(sqrt_short(x)); }
+        else if (mode == 4) { ref = 0.5f / x; got = 0.5f * rcp_exact(x); }
+        else { ref = x / c; got = div_by_uniform(x, c, rc); }
         if (!same(ref, got)) note(rep, (uint32_t)i);
     }
 }
@@ -78,14 +70,14 @@ int main() {
     Report* d; Report h;
     if (hipMalloc(&d, sizeof(Report)) != hipSuccess) { printf("no device\n"); return 1; }
     setvbuf(stdout, nullptr, _IOLBF, 0);
-    const char* names[5] = {"1/x", "sqrt(x)", "1/sqrt(x)", "", "0.5/x"};
+    const char* names[5] = {"1/x", "sqrt(x)[unused]", "1/sqrt(x)[unused]", "", "0.5/x"};
     for (int mode = 0; mode < 5; ++mode) {
         if (mode == 3) continue;
         hipMemset(d, 0, sizeof(Report));
         hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, mode, 1.0f, 1.0f, d);
         if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
         hipMemcpy(&h, d, sizeof(Report), hipMemcpyDeviceToHost);
-        printf("%-10s differing inputs: %llu", names[mode], h.bad);
+        printf("%-18s differing inputs: %llu", names[mode], h.bad);
         for (unsigned k = 0; k < 8 && k < h.bad; ++k) printf(" %08x", h.first[k]);
         printf("\n");
         ranges(h);

@@ -36,6 +36,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "exact_div.h"
 #include "rt_device.h"
 
 using namespace rtd;
@@ -53,43 +54,6 @@ __device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // GLSL built-ins as llvmpipe lowers them
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
 __device__ __forceinline__ V3 cross3(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-
-// ---- correctly rounded fp32 quotients in fewer instructions than the compiler's general sequence ----
-// The compiler expands every a / b into v_div_scale x2, v_rcp, five FMAs, v_div_fmas, v_div_fixup and a pair of
-// s_setreg that switch denormals on and off around them: about 13 instructions, because it must be right for every
-// pair (a, b). The two special cases below need less and return the same bits (tools/microbench/exact_math.hip
-// compares each with the compiler's division over all 2^32 inputs on the GPU).
-#ifndef RT_SHORT_DIV
-#define RT_SHORT_DIV 1
-#endif
-// 1 / x: hardware estimate (1 ulp), one Newton step in FMA, v_div_fixup for zeros, infinities and NaNs.
-// Equal to 1.0f / x for every one of the 2^32 inputs (denormals flushed, as in the rest of this file).
-__device__ __forceinline__ float rcp_exact(float x) {
-#if RT_SHORT_DIV
-    float y = __builtin_amdgcn_rcpf(x);
-    float e = __builtin_fmaf(-x, y, 1.0f);
-    y = __builtin_fmaf(e, y, y);
-    return __builtin_amdgcn_div_fixupf(y, x, 1.0f);
-#else
-    return 1.0f / x;
-#endif
-}
-// a / c where c is the same in every lane and rc = 1.0f / c was computed once: product, then two residual
-// corrections in FMA (the second one rounds correctly by Markstein's theorem once the first has made the
-// quotient faithful; c's significand must not be all ones, true of the integers below 2^24 used here).
-// Equal to a / c for a = 0 and for 2^-100 <= |a| < inf: outside that range the residual underflows. The
-// numerators here are sums of integers and k/255 fractions, hence zero or at least 1/255 in magnitude.
-__device__ __forceinline__ float div_by_uniform(float a, float c, float rc) {
-#if RT_SHORT_DIV
-    float q = a * rc;
-    float r = __builtin_fmaf(-c, q, a);
-    q = __builtin_fmaf(r, rc, q);
-    r = __builtin_fmaf(-c, q, a);
-    return __builtin_fmaf(r, rc, q);
-#else
-    return a / c;
-#endif
-}
 
 __device__ __forceinline__ V3 normalize3(V3 v) { float r = rcp_exact(sqrtf(dot3(v, v))); return v * r; }
 __device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) { return a + t * (b - a); }
