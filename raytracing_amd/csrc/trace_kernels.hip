@@ -214,6 +214,9 @@ __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return
 #ifndef RT_DOUBLE_STEP
 #define RT_DOUBLE_STEP 1
 #endif
+#ifndef RT_BLIND_PUSH
+#define RT_BLIND_PUSH 1
+#endif
 #ifndef RT_COLD_SPILL
 #define RT_COLD_SPILL 1
 #endif
@@ -331,7 +334,18 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     // Here the child visited next is taken directly and only the other one is deferred.
     const bool leftFirst = tL < tR;
     if (okL || okR) {
+#if RT_BLIND_PUSH
+        // The far child's entry is written whether or not both children were hit: it only counts once `top` has
+        // moved past it, which happens in the both-hit case alone. This spares a divergent branch around the write.
+        const bool both = okL && okR;
+        const uint32_t farRef = leftFirst ? refR : refL;
+        const float farT = leftFirst ? tR : tL;
+        if (L.top < kLdsStack) st.lds[L.top * 64] = make_uint2(farRef, __float_as_uint(farT));
+        else if (both) st.spill[(uint32_t)(L.top - kLdsStack) * 64u + st.lane] = ((unsigned long long)__float_as_uint(farT) << 32) | farRef;
+        L.top += both ? 1 : 0;
+#else
         if (okL && okR) push(st, L.top, leftFirst ? refR : refL, leftFirst ? tR : tL);
+#endif
         if (ITERS) L.iters++;    // the immediate pop of the chosen child (its test passes: bestT is unchanged)
         const bool takeLeft = okL && (leftFirst || !okR);
         L.cur = takeLeft ? refL : refR;
