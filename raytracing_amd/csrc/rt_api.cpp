@@ -157,7 +157,7 @@ int rt_create(int device, uint32_t width, uint32_t height, rt_context** out) {
     sp.width = width; sp.height = height;
     sp.tilesX = (width + kTile - 1) / kTile; sp.tilesY = (height + kTile - 1) / kTile;
     sp.shardRank = 0; sp.shardWorld = 1;
-    sp.rootRef = kNoRef; sp.nNode = 0;
+    sp.rootRef = kNoRef; sp.nNode = 0; sp.nInterior = 0;
     sp.bounceLimit = 4;                                   // src/Scene.cpp:19
     sp.camPos[0] = sp.camPos[1] = sp.camPos[2] = 0.0f;    // Include/Camera.h:7-11
     sp.camFacing[0] = 1.0f; sp.camFacing[1] = sp.camFacing[2] = 0.0f;
@@ -243,10 +243,22 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
         // ---- re-lay-out: one 64-byte record per interior node, interior nodes numbered consecutively in
         // the reference's pre-order (a node's left child, when interior, is the next record); an interior
         // child is referenced by its record's byte offset ----
-        std::vector<uint32_t> recordOf(nNode, 0);
+        // The first kTopRecords records are the top of the tree in breadth-first order (the nodes every ray passes),
+        // so that they are contiguous; the others follow in pre-order.
+        constexpr uint32_t kUnset = 0xffffffffu;
+        std::vector<uint32_t> recordOf(nNode, kUnset);
         uint32_t nInterior = 0;
+        if (info(0).count == 0) {
+            std::vector<uint32_t> level{0u};
+            for (size_t head = 0; head < level.size() && nInterior < kTopRecords; ++head) {
+                const uint32_t i = level[head];
+                recordOf[i] = nInterior++;
+                const uint32_t kids[2] = {i + 1, (uint32_t)info(i).ref};
+                for (uint32_t k : kids) if (info(k).count == 0) level.push_back(k);
+            }
+        }
         for (uint32_t i = 0; i < nNode; ++i)
-            if (seen[i] && info(i).count == 0) recordOf[i] = nInterior++;
+            if (seen[i] && info(i).count == 0 && recordOf[i] == kUnset) recordOf[i] = nInterior++;
         nodes.assign(nInterior, NodeRec{});
         auto childRef = [&](uint32_t child) {
             Info in = info(child);
@@ -284,7 +296,7 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // from here until the new arrays are in place the context has no scene (a failed allocation must not leave
     // the old, freed arrays reachable)
-    c->haveScene = false; c->sp.nodes = nullptr; c->sp.tris = nullptr; c->sp.rootRef = kNoRef; c->sp.nNode = 0;
+    c->haveScene = false; c->sp.nodes = nullptr; c->sp.tris = nullptr; c->sp.rootRef = kNoRef; c->sp.nNode = 0; c->sp.nInterior = 0;
     if (c->dNodes) { (void)hipFree(c->dNodes); c->dNodes = nullptr; }
     if (c->dTris) { (void)hipFree(c->dTris); c->dTris = nullptr; }
     if (!nodes.empty()) {
@@ -296,7 +308,7 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
         HIP_TRY(c, hipMemcpy(c->dTris, tris.data(), sizeof(TriRec) * nTri, hipMemcpyHostToDevice));
     }
     SceneParams& sp = c->sp;
-    sp.nodes = c->dNodes; sp.tris = c->dTris; sp.nNode = nNode;
+    sp.nodes = c->dNodes; sp.tris = c->dTris; sp.nNode = nNode; sp.nInterior = (uint32_t)nodes.size();
     if (nNode == 0) sp.rootRef = kNoRef;
     else {
         Info in = info(0);

@@ -31,6 +31,8 @@ constexpr uint32_t kNoRef = 0x7fffffffu; // "no node"
 // hard length limit in the reference. A path is cut (contributing black) after this many ray
 // segments; the parity oracle applies the same bound.
 constexpr uint32_t kMaxSegments = 4096;
+// Interior records that come first in `nodes`, in breadth-first order from the root.
+constexpr uint32_t kTopRecords = 4096;
 
 // child reference: interior -> byte offset of the child's record in `nodes` (< 2^31);
 //                  leaf -> kLeafBit | (count-1) << 27 | triStart
@@ -72,6 +74,7 @@ struct SceneParams {
     const uint32_t* sky;
     const MaterialRec* materials;   // kMaxMaterials entries
     uint32_t nNode;
+    uint32_t nInterior;          // records in `nodes`
     uint32_t rootRef;            // kNoRef for an empty scene
     float rootMin[3], rootMax[3];
     int32_t noiseW, noiseH, skySize;

@@ -3,7 +3,8 @@
 // WHAT is computed is the reference's tracer pass (src/shaders/Fragment.glsl of the reference,
 // cited below as F:<line>), with every floating-point operation in the same order and rounding
 // as that shader evaluates it under Mesa llvmpipe: reversed three-term dot products, normalize as
-// multiply by 1/sqrt, mix as a + t*(b-a), IEEE division and square root, denormals flushed, and
+// multiply by 1/sqrt, mix as a + t*(b-a), correctly rounded division (exact_div.h holds shorter sequences for
+// 1/x and a/uniform that return the same bits) and square root, denormals flushed, and
 // llvmpipe's 8-bit fixed-point bilinear texture filter. This file must be compiled with
 // -ffp-contract=off -fgpu-flush-denormals-to-zero (see Makefile; -fno-slp-vectorize is for speed
 // only); results are then bit-identical to the CPU parity oracle, and per-pixel results do not
@@ -16,7 +17,11 @@
 //     remembered from when it was pushed (same value, same comparison).
 //   * The near child is descended into directly; only the far child goes to a stack whose first
 //     kLdsStack entries live in LDS as [entry][lane] (conflict-free: each lane owns a column,
-//     8-byte entries) and whose rare deeper entries spill to a per-wave HBM area.
+//     8-byte entries) and whose rare deeper entries spill to a per-wave HBM area. Entry 0 of every column
+//     is a stopper that ends the traversal when popped, so the pop loop has no empty-stack case.
+//   * Work-groups of four waves that run independently and share one thing: an LDS copy of the first
+//     kTopLds node records (the top of the tree in breadth-first order, where a third of all visits go),
+//     so that those visits cost LDS reads instead of trips through the vector L1.
 //   * Persistent waves: the grid is sized to the machine, each wave pulls one 8x8-pixel tile at a
 //     time from per-XCD queues (one returning atomic per tile; neighbouring tiles stay on one
 //     XCD's L2; the queues hand out the tiles that were most expensive in earlier launches first),
@@ -191,7 +196,7 @@ __device__ __forceinline__ bool at_leaf(uint32_t cur) { return (int32_t)cur < 0;
 __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return state == kTraverse && cur == kNoRef; }
 
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 14
+#define RT_LDS_STACK 13
 #endif
 #ifndef RT_INT_STEPS
 #define RT_INT_STEPS 8
@@ -214,6 +219,12 @@ __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return
 #ifndef RT_DOUBLE_STEP
 #define RT_DOUBLE_STEP 1
 #endif
+#ifndef RT_WG_WAVES
+#define RT_WG_WAVES 4      // waves per work-group: they share one LDS copy of the top of the tree, nothing else
+#endif
+#ifndef RT_TOP_LDS
+#define RT_TOP_LDS 84      // interior records (the first ones: top of the tree, breadth-first) each work-group keeps in LDS
+#endif
 #ifndef RT_BLIND_PUSH
 #define RT_BLIND_PUSH 1
 #endif
@@ -224,6 +235,12 @@ __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return
 #define RT_SENTINEL 1      // stack entry 0 of every lane is a stopper, so the pop loop has no "stack empty" case
 #endif
 constexpr int kLdsStack = RT_LDS_STACK;   // stack entries per lane kept in LDS (512 B per entry per wave)
+constexpr int kWgWaves = RT_WG_WAVES;
+constexpr uint32_t kTopLds = RT_TOP_LDS;
+// five work-groups per CU (5 waves on each SIMD) must fit the 160 KiB of LDS
+static_assert((size_t)kWgWaves * kLdsStack * 512 + sizeof(MaterialRec) * kMaxMaterials + (size_t)kTopLds * sizeof(NodeRec) <= 163840 * (size_t)kWgWaves / 20,
+              "LDS per work-group too large for 20 waves per CU");
+static_assert(kTopLds <= kTopRecords, "the LDS copy must lie within the breadth-first part of the node array");
 
 // Everything a lane carries between scheduler rounds.
 struct Lane {
@@ -242,10 +259,15 @@ struct Lane {
     int iters;              // iterationsCount
 };
 
+typedef uint32_t Words4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) Words4 LdsWords4;
+
 struct StackRef {
     uint2* lds;                 // this lane's LDS column, stride 64 entries
     unsigned long long* spill;  // this wave's HBM area (wave-uniform): entry e of lane l at [(e - kLdsStack) * 64 + l]
     uint32_t lane;
+    const LdsWords4* top;       // the work-group's LDS copy of the first records of `nodes`, in 16-byte units
+    uint32_t topBytes;          // how many bytes of `nodes` that copy holds (wave-uniform)
 };
 
 // The two halves of the stack are accessed with different value types on purpose: with equal
@@ -321,9 +343,25 @@ __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, 
 // record's byte offset, so the address is the (scalar) array base plus a 32-bit lane offset.
 template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void interior_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
-    const float4* N = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sp.nodes) + L.cur);
-    float4 n0 = N[0], n1 = N[1], n2 = N[2];
-    const uint2 refs = *reinterpret_cast<const uint2*>(N + 3);      // 56 of the record's 64 bytes are read
+    // The first records (the top of the tree, which every ray passes: a third of all visits go to the first 64) are
+    // read from the work-group's LDS copy: LDS reads do not go through the texture-address unit and the vector L1,
+    // which are the busiest units of this kernel.
+    float4 n0, n1, n2;
+    uint2 refs;                                                       // 56 of the record's 64 bytes are read
+    if (kTopLds > 0 && L.cur < st.topBytes) {
+        // (an LDS-qualified pointer: these loads can only become ds_read, and the compiler cannot fold them and the
+        // loads of the other branch into FLAT loads from a selected pointer)
+        const LdsWords4* T = st.top + (L.cur >> 4);
+        const Words4 a = T[0], b = T[1], c = T[2], d = T[3];
+        n0 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        n1 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+        n2 = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
+        refs = make_uint2(d.x, d.y);
+    } else {
+        const float4* N = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sp.nodes) + L.cur);
+        n0 = N[0]; n1 = N[1]; n2 = N[2];
+        refs = *reinterpret_cast<const uint2*>(N + 3);
+    }
     if (COUNT) tl.boxes += 2;
     float tL, tR;
     bool hL = hit_box(L.ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tL);
@@ -412,7 +450,7 @@ __global__ void prepare_frames_kernel(SceneParams sp, FrameParams* __restrict__ 
 // renders one frame, whose parameters then live in scalar registers; ITERS: the shader's iterationsCount is
 // kept (needed by the tallies, the id pass and the heat-map view of bounce limit 0 only).
 template <bool COUNT, bool IDS, bool SINGLE, bool ITERS>
-__global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
+__global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
                                                    float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
                                                    int32_t* __restrict__ ids /* IDS only: [slot][3] */,
                                                    uint2* __restrict__ spillArea /* [gridDim.x][kMaxStack-kLdsStack][64] */,
@@ -420,20 +458,29 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
                                                    uint32_t nGroups /* tiles of this shard */, uint32_t tallyStride,
                                                    const uint32_t* __restrict__ order /* [nGroups] tile hand-out order, or NULL for 0,1,2.. */,
                                                    uint32_t* __restrict__ tileCost /* [nGroups] rays traced per tile are added here, or NULL */) {
-    __shared__ uint2 lds_stack[kLdsStack * 64];
+    // The waves of a work-group run independently (each is its own persistent worker); they only share the LDS
+    // copies of the material table and of the top of the tree, filled here before the one barrier of the kernel.
+    __shared__ uint2 lds_stack[kWgWaves * kLdsStack * 64];
     __shared__ MaterialRec lds_mat[kMaxMaterials];
-    const uint32_t lane = threadIdx.x;
+    __shared__ Words4 lds_top[kTopLds > 0 ? kTopLds * 4 : 1];
+    const uint32_t lane = threadIdx.x & 63u, waveInGroup = threadIdx.x >> 6;
+    const uint32_t wave = blockIdx.x * (uint32_t)kWgWaves + waveInGroup;      // index into the per-wave arrays
+    const uint32_t nTop = min(kTopLds, sp.nInterior);
     StackRef st;
-    st.lds = lds_stack + lane;
-    st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)blockIdx.x * (kMaxStack - kLdsStack) * 64;
+    st.lds = lds_stack + waveInGroup * (uint32_t)(kLdsStack * 64) + lane;
+    st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)wave * (kMaxStack - kLdsStack) * 64;
     st.lane = lane;
+    st.top = (const LdsWords4*)lds_top;
+    st.topBytes = nTop * (uint32_t)sizeof(NodeRec);
 #if RT_SENTINEL
     st.lds[0] = make_uint2(kNoRef, __float_as_uint(-INFINITY));      // the stopper below every traversal's entries
 #endif
 
     // the material table is small and read at every hit: keep a copy in LDS
-    for (uint32_t j = lane; j < (uint32_t)(sizeof(MaterialRec) / 4 * kMaxMaterials); j += 64u)
+    for (uint32_t j = threadIdx.x; j < (uint32_t)(sizeof(MaterialRec) / 4 * kMaxMaterials); j += blockDim.x)
         reinterpret_cast<uint32_t*>(lds_mat)[j] = reinterpret_cast<const uint32_t*>(sp.materials)[j];
+    for (uint32_t j = threadIdx.x; j < nTop * 4u; j += blockDim.x)
+        lds_top[j] = reinterpret_cast<const Words4*>(sp.nodes)[j];
     __syncthreads();
 
     // Per-launch constants are the same in every lane: computed with vector instructions (there
@@ -709,7 +756,7 @@ __global__ __launch_bounds__(64, RT_MIN_WAVES) void trace_kernel(SceneParams sp,
         if (!COUNT && s != (int)kRays) continue;
         uint32_t v = vals[s];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) tally[(size_t)s * tallyStride + blockIdx.x] += v;
+        if (lane == 0) tally[(size_t)s * tallyStride + wave] += v;
     }
 }
 
@@ -769,9 +816,9 @@ uint32_t ResidentWaves() {
     int dev = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false, true, false>, 64, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false, true, false>, 64 * kWgWaves, 0) != hipSuccess) return 0;
     if (perCu < 1) perCu = 1;
-    return (uint32_t)cus * (uint32_t)perCu;
+    return (uint32_t)cus * (uint32_t)perCu * (uint32_t)kWgWaves;
 }
 
 void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames) {
@@ -783,7 +830,7 @@ void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const Sc
                  const uint32_t* order, uint32_t* tileCost) {
     float4* a = static_cast<float4*>(accum);
     uint2* sa = static_cast<uint2*>(spillArea);
-    dim3 grid(nWaves), block(64);
+    dim3 grid((nWaves + (uint32_t)kWgWaves - 1u) / (uint32_t)kWgWaves), block(64 * kWgWaves);     // the per-wave arrays hold a multiple of kWgWaves
     const bool single = nFrames == 1u;
     const bool heat = sp.bounceLimit == 0u;        // the only view that shows iterationsCount
 #define RT_LAUNCH(C, I, S, T) hipLaunchKernelGGL((trace_kernel<C, I, S, T>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost)
