@@ -196,7 +196,7 @@ __device__ __forceinline__ bool at_leaf(uint32_t cur) { return (int32_t)cur < 0;
 __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return state == kTraverse && cur == kNoRef; }
 
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 13
+#define RT_LDS_STACK 12
 #endif
 #ifndef RT_INT_STEPS
 #define RT_INT_STEPS 8
@@ -223,7 +223,7 @@ __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return
 #define RT_WG_WAVES 4      // waves per work-group: they share one LDS copy of the top of the tree, nothing else
 #endif
 #ifndef RT_TOP_LDS
-#define RT_TOP_LDS 84      // interior records (the first ones: top of the tree, breadth-first) each work-group keeps in LDS
+#define RT_TOP_LDS 104     // interior records (the first ones: top of the tree, breadth-first) each work-group keeps in LDS
 #endif
 #ifndef RT_BLIND_PUSH
 #define RT_BLIND_PUSH 1
@@ -237,8 +237,12 @@ __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return
 constexpr int kLdsStack = RT_LDS_STACK;   // stack entries per lane kept in LDS (512 B per entry per wave)
 constexpr int kWgWaves = RT_WG_WAVES;
 constexpr uint32_t kTopLds = RT_TOP_LDS;
-// five work-groups per CU (5 waves on each SIMD) must fit the 160 KiB of LDS
-static_assert((size_t)kWgWaves * kLdsStack * 512 + sizeof(MaterialRec) * kMaxMaterials + (size_t)kTopLds * sizeof(NodeRec) <= 163840 * (size_t)kWgWaves / 20,
+// 20 waves per CU (5 on each SIMD) must fit the 160 KiB of LDS, which is handed out in granules of 1 280 bytes:
+// 128 granules per CU, 25 per work-group of four waves = 32 000 bytes. One granule more and only four work-groups
+// fit (measured: 7.64 instead of 6.97 ms per frame).
+constexpr size_t kLdsGranule = 1280, kLdsPerGroup = (163840 / kLdsGranule) / (20 / kWgWaves) * kLdsGranule;
+static_assert(20 % kWgWaves == 0, "work-groups must divide the 20 waves of a CU");
+static_assert((size_t)kWgWaves * kLdsStack * 512 + sizeof(MaterialRec) * kMaxMaterials + (size_t)kTopLds * sizeof(NodeRec) <= kLdsPerGroup,
               "LDS per work-group too large for 20 waves per CU");
 static_assert(kTopLds <= kTopRecords, "the LDS copy must lie within the breadth-first part of the node array");
 
