@@ -240,10 +240,11 @@ constexpr uint32_t kTopLds = RT_TOP_LDS;
 // 20 waves per CU (5 on each SIMD) must fit the 160 KiB of LDS, which is handed out in granules of 1 280 bytes:
 // 128 granules per CU, 25 per work-group of four waves = 32 000 bytes. One granule more and only four work-groups
 // fit (measured: 7.64 instead of 6.97 ms per frame).
-constexpr size_t kLdsGranule = 1280, kLdsPerGroup = (163840 / kLdsGranule) / (20 / kWgWaves) * kLdsGranule;
-static_assert(20 % kWgWaves == 0, "work-groups must divide the 20 waves of a CU");
+constexpr size_t kWavesPerCu = 4 * RT_MIN_WAVES;
+constexpr size_t kLdsGranule = 1280, kLdsPerGroup = (163840 / kLdsGranule) / (kWavesPerCu / kWgWaves) * kLdsGranule;
+static_assert(kWavesPerCu % kWgWaves == 0, "work-groups must divide the waves of a CU");
 static_assert((size_t)kWgWaves * kLdsStack * 512 + sizeof(MaterialRec) * kMaxMaterials + (size_t)kTopLds * sizeof(NodeRec) <= kLdsPerGroup,
-              "LDS per work-group too large for 20 waves per CU");
+              "LDS per work-group too large for the intended number of waves per CU");
 static_assert(kTopLds <= kTopRecords, "the LDS copy must lie within the breadth-first part of the node array");
 
 // Everything a lane carries between scheduler rounds.
