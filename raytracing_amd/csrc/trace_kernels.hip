@@ -356,7 +356,7 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     if (kTopLds > 0 && L.cur < st.topBytes) {
         // (an LDS-qualified pointer: these loads can only become ds_read, and the compiler cannot fold them and the
         // loads of the other branch into FLAT loads from a selected pointer)
-        const LdsWords4* T = st.top + (L.cur >> 4);
+        const LdsWords4* T = (const LdsWords4*)((const __attribute__((address_space(3))) char*)st.top + L.cur);
         const Words4 a = T[0], b = T[1], c = T[2], d = T[3];
         n0 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
         n1 = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
