@@ -77,14 +77,28 @@ __device__ __forceinline__ uint32_t Hash(uint32_t x) {      // F:96-105
 }
 __device__ __forceinline__ uint32_t Hashf(float f) { return Hash(__float_as_uint(f)); }
 
+// Products of two numbers below 2^24 (texel rows x texture width, triangle index x record size, tile quotients,
+// 8-bit channels x weights): the 24-bit multiplier gives the same 32-bit result as v_mul_lo_u32 at a quarter of its
+// issue cost.
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+
 // ---- llvmpipe's default LINEAR filter on 8-bit formats: 8.8 fixed-point coordinates, rounded
 // 8-bit lerps, x first then y, result scaled by 1/255 ----
-__device__ __forceinline__ int lerp8(int a, int b, int w) { return (a + (((b - a) * w + 128) >> 8)) & 255; }
+// The lerp is a + (((b - a) * w + 128) >> 8) with an arithmetic shift. Adding a * 256 inside the shift gives the
+// same value for all a, b, w in 0..255 without a signed intermediate: (a * (256 - w) + b * w + 128) >> 8, at most
+// 255. In that form two channels that sit 16 bits apart in a register are filtered by the same two multiply-adds:
+// every field stays below 2^16, nothing carries into its neighbour.
+__device__ __forceinline__ uint32_t lerp8(uint32_t a, uint32_t b, uint32_t w, uint32_t iw /* 256 - w */) {
+    return (mul24(b, w) + (mul24(a, iw) + 128u)) >> 8;
+}
+__device__ __forceinline__ uint32_t lerp8x2(uint32_t a, uint32_t b, uint32_t w, uint32_t iw) {      // fields at bits 0..7 and 16..23
+    return ((mul24(b, w) + (mul24(a, iw) + 0x00800080u)) >> 8) & 0x00ff00ffu;
+}
 
 __device__ __forceinline__ uint32_t bilerp_rgbx(uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, int wx, int wy, int ch) {
-    int sh = ch * 8;
-    int a = (t00 >> sh) & 255, b = (t10 >> sh) & 255, c = (t01 >> sh) & 255, d = (t11 >> sh) & 255;
-    return (uint32_t)lerp8(lerp8(a, b, wx), lerp8(c, d, wx), wy);
+    const uint32_t sh = (uint32_t)ch * 8u, ux = (uint32_t)wx, uy = (uint32_t)wy, ix = 256u - ux, iy = 256u - uy;
+    const uint32_t a = (t00 >> sh) & 255u, b = (t10 >> sh) & 255u, c = (t01 >> sh) & 255u, d = (t11 >> sh) & 255u;
+    return lerp8(lerp8(a, b, ux, ix), lerp8(c, d, ux, ix), uy, iy);
 }
 
 __device__ __forceinline__ void coord_repeat(float c, int n, int& i0, int& i1, int& w) {
@@ -103,9 +117,6 @@ __device__ __forceinline__ void coord_repeat(float c, int n, int& i0, int& i1, i
 // separate so that a caller can request several footprints before it waits for any of them.
 struct Texels { uint32_t t00, t10, t01, t11; int wx, wy; };
 
-// Products of two numbers below 2^24 (texel rows x texture width, triangle index x record size, tile quotients):
-// the 24-bit multiplier gives the same 32-bit result as v_mul_lo_u32 at a quarter of its issue cost.
-__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
 // n / d and n % d for n < 2^24 and a divisor d that is the same in every lane, with rd = 1.0f / float(d): the float
 // product is within one of the quotient (its error is at most n/d * 2^-23 <= 1 for d >= 2, none for d = 1), and
@@ -122,7 +133,14 @@ __device__ __forceinline__ void divmod_uniform(uint32_t n, uint32_t d, float rd,
 __device__ __forceinline__ float resolve(const Texels& q, int ch) {
     return (float)bilerp_rgbx(q.t00, q.t10, q.t01, q.t11, q.wx, q.wy, ch) * (float)(1.0 / 255.0);
 }
-__device__ __forceinline__ V3 resolve3(const Texels& q) { return mk(resolve(q, 0), resolve(q, 1), resolve(q, 2)); }
+// All three channels of a footprint: red and blue together (bits 0..7 and 16..23 of a texel), green on its own.
+__device__ __forceinline__ V3 resolve3(const Texels& q) {
+    const uint32_t ux = (uint32_t)q.wx, uy = (uint32_t)q.wy, ix = 256u - ux, iy = 256u - uy, rb = 0x00ff00ffu;
+    const uint32_t prb = lerp8x2(lerp8x2(q.t00 & rb, q.t10 & rb, ux, ix), lerp8x2(q.t01 & rb, q.t11 & rb, ux, ix), uy, iy);
+    const uint32_t pg = lerp8(lerp8((q.t00 >> 8) & 255u, (q.t10 >> 8) & 255u, ux, ix), lerp8((q.t01 >> 8) & 255u, (q.t11 >> 8) & 255u, ux, ix), uy, iy);
+    const float k = (float)(1.0 / 255.0);
+    return mk((float)(prb & 255u) * k, (float)pg * k, (float)(prb >> 16) * k);
+}
 
 __device__ __forceinline__ Texels fetch_noise(const SceneParams& sp, float s, float t) {   // texture(u_RgbNoise, ..)
     int x0, x1, y0, y1;
