@@ -261,15 +261,6 @@ __device__ __forceinline__ bool awaits_shading(int state, uint32_t cur) { return
 #ifndef RT_TOP_LDS
 #define RT_TOP_LDS 104     // interior records (the first ones: top of the tree, breadth-first) each work-group keeps in LDS
 #endif
-#ifndef RT_BLIND_PUSH
-#define RT_BLIND_PUSH 1
-#endif
-#ifndef RT_COLD_SPILL
-#define RT_COLD_SPILL 1
-#endif
-#ifndef RT_SENTINEL
-#define RT_SENTINEL 1      // stack entry 0 of every lane is a stopper, so the pop loop has no "stack empty" case
-#endif
 constexpr int kLdsStack = RT_LDS_STACK;   // stack entries per lane kept in LDS (512 B per entry per wave)
 constexpr int kWgWaves = RT_WG_WAVES;
 constexpr uint32_t kTopLds = RT_TOP_LDS;
@@ -311,16 +302,11 @@ struct StackRef {
     uint32_t topBytes;          // how many bytes of `nodes` that copy holds (wave-uniform)
 };
 
-// The two halves of the stack are accessed with different value types on purpose: with equal
-// types the compiler merges the LDS and the HBM access into one FLAT instruction on a selected
-// pointer, which is slower than ds_read/ds_write and drags the LDS traffic through the vector
-// memory path.
-__device__ __forceinline__ void push(const StackRef& st, int& top, uint32_t ref, float t) {
-    if (top < kLdsStack) st.lds[top * 64] = make_uint2(ref, __float_as_uint(t));
-    else st.spill[(uint32_t)(top - kLdsStack) * 64u + st.lane] = ((unsigned long long)__float_as_uint(t) << 32) | ref;
-    ++top;
-}
-
+// The two halves of the stack (LDS entries as uint2, spilled entries as one 64-bit word) are accessed with
+// different value types on purpose: with equal types the compiler merges the LDS and the HBM access into one FLAT
+// instruction on a selected pointer, which is slower than ds_read/ds_write and drags the LDS traffic through the
+// vector memory path.
+//
 // Pops deferred nodes until one is still worth visiting (F:277-283 with the entry distance kept
 // from push time). Leaves the next reference, or kNoRef when the traversal is over, in L.cur.
 //
@@ -329,7 +315,6 @@ __device__ __forceinline__ void push(const StackRef& st, int& top, uint32_t ref,
 // empty stack; a traversal starts with top = 1.
 template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
-#if RT_SENTINEL
     for (;;) {
         --L.top;
         uint2 e = st.lds[min(L.top, kLdsStack - 1) * 64];
@@ -337,9 +322,7 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
             // (the empty asm keeps the address arithmetic of this rare case inside the branch: without it the
             // compiler maintains the spill index in the loop for every pop)
             uint32_t deep = (uint32_t)(L.top - kLdsStack);
-#if RT_COLD_SPILL
             asm volatile("" : "+v"(deep));
-#endif
             unsigned long long w = st.spill[deep * 64u + st.lane];
             e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
         }
@@ -348,27 +331,12 @@ __device__ __forceinline__ void pop_next(const StackRef& st, Lane& L) {
         L.cur = e.x;
         break;
     }
-#else
-    for (;;) {
-        if (L.top == 0) { L.cur = kNoRef; return; }
-        --L.top;
-        uint2 e = st.lds[min(L.top, kLdsStack - 1) * 64];
-        if (L.top >= kLdsStack) {
-            unsigned long long w = st.spill[(uint32_t)(L.top - kLdsStack) * 64u + st.lane];
-            e = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
-        }
-        if (ITERS) L.iters++;
-        if (__uint_as_float(e.y) >= L.bestT) continue;
-        L.cur = e.x;
-        return;
-    }
-#endif
 }
 
 // Starts the traversal of L.ray: the root's own box test (the first pop of F:276-283).
 template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, Tally& tl) {
-    L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0; L.top = RT_SENTINEL ? 1 : 0; L.cur = kNoRef;
+    L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0; L.top = 1; L.cur = kNoRef;
     L.state = kTraverse;
     tl.rays++;
     if (sp.rootRef != kNoRef) {
@@ -385,8 +353,8 @@ __device__ __forceinline__ void begin_traversal(const SceneParams& sp, Lane& L, 
 template <bool COUNT, bool ITERS>
 __device__ __forceinline__ void interior_step(const SceneParams& sp, const StackRef& st, Lane& L, Tally& tl) {
     // The first records (the top of the tree, which every ray passes: a third of all visits go to the first 64) are
-    // read from the work-group's LDS copy: LDS reads do not go through the texture-address unit and the vector L1,
-    // which are the busiest units of this kernel.
+    // read from the work-group's LDS copy: LDS reads do not go through the texture-address unit and the vector L1
+    // (30 % fewer L1 accesses per frame on the benchmark scene).
     float4 n0, n1, n2;
     uint2 refs;                                                       // 56 of the record's 64 bytes are read
     if (kTopLds > 0 && L.cur < st.topBytes) {
@@ -413,7 +381,6 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     // Here the child visited next is taken directly and only the other one is deferred.
     const bool leftFirst = tL < tR;
     if (okL || okR) {
-#if RT_BLIND_PUSH
         // The far child's entry is written whether or not both children were hit: it only counts once `top` has
         // moved past it, which happens in the both-hit case alone. This spares a divergent branch around the write.
         const bool both = okL && okR;
@@ -422,9 +389,6 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
         if (L.top < kLdsStack) st.lds[L.top * 64] = make_uint2(farRef, __float_as_uint(farT));
         else if (both) st.spill[(uint32_t)(L.top - kLdsStack) * 64u + st.lane] = ((unsigned long long)__float_as_uint(farT) << 32) | farRef;
         L.top += both ? 1 : 0;
-#else
-        if (okL && okR) push(st, L.top, leftFirst ? refR : refL, leftFirst ? tR : tL);
-#endif
         if (ITERS) L.iters++;    // the immediate pop of the chosen child (its test passes: bestT is unchanged)
         const bool takeLeft = okL && (leftFirst || !okR);
         L.cur = takeLeft ? refL : refR;
@@ -513,9 +477,7 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
     st.lane = lane;
     st.top = (const LdsWords4*)lds_top;
     st.topBytes = nTop * (uint32_t)sizeof(NodeRec);
-#if RT_SENTINEL
     st.lds[0] = make_uint2(kNoRef, __float_as_uint(-INFINITY));      // the stopper below every traversal's entries
-#endif
 
     // the material table is small and read at every hit: keep a copy in LDS
     for (uint32_t j = threadIdx.x; j < (uint32_t)(sizeof(MaterialRec) / 4 * kMaxMaterials); j += blockDim.x)
