@@ -205,3 +205,35 @@ def test_bounce_limit_32_and_a_long_launch_bit_exact():
         r.render(0, seeds)
     assert differing_pixels(g.read_accum(), o.read_accum()) == 0
     g.close()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (8, 600), (5, 333), (1500, 9), (2047, 3), (1, 257), (4100, 8)],
+                         ids=lambda s: "%dx%d" % s)
+def test_extreme_image_shapes_bit_exact(size):
+    """One tile column, one tile row, single pixels: the tile -> pixel arithmetic at its edges, alone and in 3 shards."""
+    from raytracing_amd import sharding
+    import torch
+    W, H = size
+    sc = make_scene("sponza_like", target_tris=6000)
+    o = Oracle(W, H, threads=16)
+    setup(o, sc, NOISE, SKY, bounce_limit=3)
+    o.render(0, SEEDS[:2])
+    want = o.read_accum()
+    g = ra.Renderer(W, H)
+    setup(g, sc, NOISE, SKY, bounce_limit=3)
+    g.render(0, SEEDS[:2])
+    assert differing_pixels(g.read_accum(), want) == 0
+    g.close()
+    world = 3
+    per = sharding.shard_floats(W, H, world)
+    flat = np.zeros(world * per, dtype=np.float32)
+    for rank in range(world):
+        r = ra.Renderer(W, H)
+        setup(r, sc, NOISE, SKY, bounce_limit=3)
+        r.set_shard(rank, world)
+        r.render(0, SEEDS[:2])
+        t = torch.empty(per, dtype=torch.float32, device="cuda")
+        r.export_shard(t.data_ptr()); r.sync()
+        flat[rank * per:(rank + 1) * per] = t.cpu().numpy()
+        r.close()
+    assert differing_pixels(sharding.assemble_numpy(flat, W, H, world), want) == 0
