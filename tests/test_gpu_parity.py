@@ -237,3 +237,28 @@ def test_extreme_image_shapes_bit_exact(size):
         flat[rank * per:(rank + 1) * per] = t.cpu().numpy()
         r.close()
     assert differing_pixels(sharding.assemble_numpy(flat, W, H, world), want) == 0
+
+
+def test_deep_stack_spills_to_memory_bit_exact():
+    """A deck of parallel quads facing the camera: every ray enters both children of every node on its way down, so
+    the deferred-node stack reaches the depth of the tree, beyond the entries kept on chip, on every primary ray."""
+    n = 20000
+    x = (1.0 + 0.001 * np.arange(n, dtype=np.float64)).astype(np.float32)
+    lo, hi = np.float32(-6.0), np.float32(6.0)
+    tri9 = np.zeros((2 * n, 9), dtype=np.float32)
+    tri9[0::2] = np.stack([x, np.full(n, lo), np.full(n, lo), x, np.full(n, hi), np.full(n, lo), x, np.full(n, hi), np.full(n, hi)], 1)
+    tri9[1::2] = np.stack([x, np.full(n, lo), np.full(n, lo), x, np.full(n, hi), np.full(n, hi), x, np.full(n, lo), np.full(n, hi)], 1)
+    mats = np.zeros((2, 11), dtype=np.float32)
+    mats[0] = [0.8, 0.7, 0.6, 1, 1, 1, 1.0, 0.0, 0.0, 0.0, 0]       # lambertian
+    mats[1] = [0.9, 0.9, 1.0, 1, 1, 1, 0.0, 0.5, 0.9, 1.5, 0]       # glass: paths go through the whole deck
+    slots = (np.arange(2 * n) // 2 % 7 == 0).astype(np.int32)
+    sc = ra.build_scene(tri9, slots, mats, build_threads=4)
+    assert sc.stats["max_depth"] >= 14
+    W, H = 72, 40
+    g, o = ra.Renderer(W, H), Oracle(W, H, threads=16)
+    for r in (g, o):
+        setup(r, sc, NOISE, SKY, bounce_limit=3)
+        r.render(0, SEEDS[:2])
+    assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+    assert (g.primary_ids(SEEDS[0]) == o.primary_ids(SEEDS[0])).all()
+    g.close()
