@@ -28,13 +28,23 @@ namespace {
 
 constexpr int kLevels = 4;
 
-__global__ void down_kernel(const float4* __restrict__ accum, float4* __restrict__ tmp, int W, int H, int w, int h) {
+// The accumulation image as the tracer keeps it: 8x8-pixel tiles, tile-major (or row-major when tilesX == 0).
+struct AccumView {
+    const float4* p;
+    int W, tilesX;
+    __device__ __forceinline__ float4 at(int x, int y) const {
+        if (tilesX == 0) return p[(size_t)y * W + x];
+        return p[((size_t)(y >> 3) * tilesX + (x >> 3)) * 64 + ((y & 7) << 3) + (x & 7)];
+    }
+};
+
+__global__ void down_kernel(AccumView accum, float4* __restrict__ tmp, int W, int H, int w, int h) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     int sx = (int)floorf(((float)x + 0.5f) * ((float)W / (float)w));
     int sy = (int)floorf(((float)y + 0.5f) * ((float)H / (float)h));
     sx = min(sx, W - 1); sy = min(sy, H - 1);
-    float4 s = accum[(size_t)sy * W + sx];
+    float4 s = accum.at(sx, sy);
     tmp[(size_t)y * W + x] = make_float4(s.x, s.y, s.z, 0.0f);
 }
 
@@ -129,12 +139,12 @@ __device__ __forceinline__ float4 up_sample(const LevelView& L, int x, int y, in
 
 // Fi:17-30, with the four up-blits of main.cpp:262-268 evaluated in place: the reference first writes each level,
 // enlarged to the whole window, into a texture of its own and reads the four back here; the values added are the same.
-__global__ void final_kernel(const float4* __restrict__ accum, LevelView l0, LevelView l1, LevelView l2, LevelView l3,
+__global__ void final_kernel(AccumView accum, LevelView l0, LevelView l1, LevelView l2, LevelView l3,
                              float4* __restrict__ tmp, int W, int H) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= W || y >= H) return;
     const size_t i = (size_t)y * W + x;
-    float4 s = accum[i];
+    float4 s = accum.at(x, y);
     const float g = 1.0f / 1.61803f;
     float4 a = up_sample(l0, x, y, W, H), b = up_sample(l1, x, y, W, H), c = up_sample(l2, x, y, W, H), d = up_sample(l3, x, y, W, H);
     float r = powf(s.x, g), gr = powf(s.y, g), bl = powf(s.z, g);
@@ -212,7 +222,9 @@ int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height,
     return RT_OK;
 }
 
-int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint32_t height, int bloomOn, void** scratch,
+// `accumImage` is the tile-major accumulation image when tilesX > 0 (bloom chain: the kernels index it directly) and a
+// row-major copy of it when tilesX == 0 (needed for the raw path, whose image is handed out as it is).
+int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint32_t width, uint32_t height, int bloomOn, void** scratch,
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err) {
     const size_t n = (size_t)width * height;
     if (!*scratch) *scratch = new PostScratch();
@@ -234,7 +246,9 @@ int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint
         s->W = width; s->H = height;
     }
     const int W = (int)width, H = (int)height;
-    const float4* accum = static_cast<const float4*>(accumLinear);
+    if (!bloomOn && tilesX != 0) { err = "the raw path needs the row-major image"; return RT_ERR_INVALID; }
+    const float4* accum = static_cast<const float4*>(accumImage);
+    const AccumView view{accum, (int)width, (int)tilesX};
     const dim3 b2(32, 8);
     auto grid2 = [&](int w, int h) { return dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)); };
     if (bloomOn) {
@@ -243,7 +257,7 @@ int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint
         Regions(W, H, rw, rh);
         for (int i = 0; i < kLevels; ++i) {
             const int w = W / ds[i], h = H / ds[i];
-            if (w > 0 && h > 0) hipLaunchKernelGGL(down_kernel, grid2(w, h), b2, 0, st, accum, s->tmp, W, H, w, h);
+            if (w > 0 && h > 0) hipLaunchKernelGGL(down_kernel, grid2(w, h), b2, 0, st, view, s->tmp, W, H, w, h);
             const int pw = min(W, rw[i] + kApron), ph = min(H, rh[i] + kApron);
             hipLaunchKernelGGL(pre_kernel, grid2(pw, ph), b2, 0, st, s->tmp, s->pre, W, pw, ph);
             hipLaunchKernelGGL(blur_kernel, grid2(rw[i], rh[i]), dim3(kBlurTX, kBlurTY), 0, st, s->pre, s->tmp, W, H, pw, ph, rw[i], rh[i]);
@@ -256,7 +270,7 @@ int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint
         const int dsz[kLevels] = {5, 10, 20, 40};
         LevelView lv[kLevels];
         for (int i = 0; i < kLevels; ++i) lv[i] = LevelView{s->snap[i], W / dsz[i], H / dsz[i], s->sw[i], s->sh[i]};
-        hipLaunchKernelGGL(final_kernel, grid2(W, H), b2, 0, st, accum, lv[0], lv[1], lv[2], lv[3], s->tmp, W, H);
+        hipLaunchKernelGGL(final_kernel, grid2(W, H), b2, 0, st, view, lv[0], lv[1], lv[2], lv[3], s->tmp, W, H);
         shown = s->tmp;
     }
     if (hipGetLastError() != hipSuccess) { err = "kernel launch failed"; return RT_ERR_DEVICE; }

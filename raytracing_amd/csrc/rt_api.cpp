@@ -27,7 +27,7 @@ uint32_t ResidentWaves();
 void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots);
 void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t width, uint32_t height, uint32_t tilesX, uint32_t world,
                   uint32_t shardTiles, bool toTiled);
-int RunPostprocess(hipStream_t st, const void* accumLinear, uint32_t width, uint32_t height, int bloomOn, void** scratch,
+int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint32_t width, uint32_t height, int bloomOn, void** scratch,
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 void FreePostprocess(void** scratch);
@@ -557,10 +557,16 @@ int rt_postprocess(rt_context* c, int bloom_on, float* rgba_out, uint8_t* rgb8_o
     if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_postprocess: only on an unsharded context");
     if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_postprocess: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
-    LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, false);
-    HIP_TRY(c, hipGetLastError());
     std::string err;
-    int rc = RunPostprocess(c->stream, c->dLinear, c->width, c->height, bloom_on, &c->postScratch, rgba_out, rgb8_out, err);
+    int rc;
+    if (bloom_on) {
+        // the chain reads the tile-major image as it is
+        rc = RunPostprocess(c->stream, c->dAccum, c->sp.tilesX, c->width, c->height, 1, &c->postScratch, rgba_out, rgb8_out, err);
+    } else {
+        LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, false);
+        HIP_TRY(c, hipGetLastError());
+        rc = RunPostprocess(c->stream, c->dLinear, 0, c->width, c->height, 0, &c->postScratch, rgba_out, rgb8_out, err);
+    }
     if (rc != RT_OK) return Fail(c, rc, "rt_postprocess: %s", err.c_str());
     return RT_OK;
 }
