@@ -372,6 +372,12 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
         refs = *reinterpret_cast<const uint2*>(N + 3);
     }
     if (COUNT) tl.boxes += 2;
+#ifdef RT_PROBE_TOP
+    // Measurement build only (tools/top_probe.py): how many visits go to the first 32 / 64 / 128 / 256 / 1024 / 4096
+    // records, added on top of six of the ordinary tallies (subtract the tallies of an ordinary build).
+    if (COUNT) { tl.sky += (L.cur < 32u * 64u); tl.noise += (L.cur < 64u * 64u); tl.hits += (L.cur < 128u * 64u);
+                 tl.paths += (L.cur < 256u * 64u); tl.tris += (L.cur < 1024u * 64u); tl.pops += (L.cur < 4096u * 64u); }
+#endif
     float tL, tR;
     bool hL = hit_box(L.ray, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tL);
     bool hR = hit_box(L.ray, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tR);

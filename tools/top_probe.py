@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Prints the device counters of a few counted frames of the benchmark workload (library chosen by RT_LIB_PATH).
-Used with a probe build (-DRT_PROBE_TOP) whose extra counts show how many node visits fall into the first records."""
+Run it once with the ordinary library and once with a probe build (tools/build_variant.sh probe -DRT_PROBE_TOP=1,
+RT_LIB_PATH=build_variants/probe.so): the differences of sky_fetches, noise_fetches, hits, paths, tris_tested and
+node_pops are the node visits that went to the first 32, 64, 128, 256, 1024 and 4096 records."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
