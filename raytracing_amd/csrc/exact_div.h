@@ -8,6 +8,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #ifndef RT_SHORT_DIV
 #define RT_SHORT_DIV 1
@@ -42,6 +43,24 @@ __device__ __forceinline__ float div_by_uniform(float a, float c, float rc) {
     return __builtin_fmaf(r, rc, q);
 #else
     return a / c;
+#endif
+}
+
+// sqrt(x): hardware reciprocal square root (1 ulp), product, one residual correction in FMA: 5 instructions in a
+// chain instead of the compiler's 17. Correctly rounded for every x in [2^-100, inf); everything else (zero, tiny and
+// negative values, infinities, NaNs) takes the ordinary sqrtf in a branch that is skipped when no lane needs it.
+// Equal to sqrtf(x) for every one of the 2^32 inputs.
+__device__ __forceinline__ float sqrt_exact(float x) {
+#if RT_SHORT_DIV
+    float r = __builtin_amdgcn_rsqf(x);
+    float s = x * r;
+    float h = 0.5f * r;
+    float e = __builtin_fmaf(-s, s, x);
+    float y = __builtin_fmaf(e, h, s);
+    if (__builtin_expect(!(x >= 0x1p-100f && x < __builtin_inff()), 0)) y = sqrtf(x);
+    return y;
+#else
+    return sqrtf(x);
 #endif
 }
 

@@ -38,7 +38,8 @@ __device__ void note(Report* rep, uint32_t bits) {
     atomicAdd(&rep->byExp[bits >> 23], 1u);       // sign and exponent of the input
 }
 
-// mode 0: 1/x   1: sqrt(x)   2: 1/sqrt(x) as two roundings   3: x / c   4: 0.5/x
+// mode 0: 1/x   1, 2: the short square root without its fallback (not used)   3: x / c   4: 0.5/x
+// 5: sqrt(x)   6: 1/sqrt(x) as two roundings
 __global__ void check(int mode, float c, float rc, Report* rep) {
     const uint64_t n = 1ull << 32, stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -48,6 +49,8 @@ __global__ void check(int mode, float c, float rc, Report* rep) {
         else if (mode == 1) { ref = sqrtf(x); got = sqrt_short(x); }
         else if (mode == 2) { ref = 1.0f / sqrtf(x); got = rcp_exact(sqrt_short(x)); }
         else if (mode == 4) { ref = 0.5f / x; got = 0.5f * rcp_exact(x); }
+        else if (mode == 5) { ref = sqrtf(x); got = sqrt_exact(x); }
+        else if (mode == 6) { ref = 1.0f / sqrtf(x); got = rcp_exact(sqrt_exact(x)); }
         else { ref = x / c; got = div_by_uniform(x, c, rc); }
         if (!same(ref, got)) note(rep, (uint32_t)i);
     }
@@ -70,8 +73,8 @@ int main() {
     Report* d; Report h;
     if (hipMalloc(&d, sizeof(Report)) != hipSuccess) { printf("no device\n"); return 1; }
     setvbuf(stdout, nullptr, _IOLBF, 0);
-    const char* names[5] = {"1/x", "sqrt(x)[unused]", "1/sqrt(x)[unused]", "", "0.5/x"};
-    for (int mode = 0; mode < 5; ++mode) {
+    const char* names[7] = {"1/x", "sqrt_short(x)[unused]", "1/sqrt_short(x)[unused]", "", "0.5/x", "sqrt(x)", "1/sqrt(x)"};
+    for (int mode = 0; mode < 7; ++mode) {
         if (mode == 3) continue;
         hipMemset(d, 0, sizeof(Report));
         hipLaunchKernelGGL(check, dim3(4096), dim3(256), 0, 0, mode, 1.0f, 1.0f, d);

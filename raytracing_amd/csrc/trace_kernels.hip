@@ -60,14 +60,14 @@ __device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
 __device__ __forceinline__ V3 cross3(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 
-__device__ __forceinline__ V3 normalize3(V3 v) { float r = rcp_exact(sqrtf(dot3(v, v))); return v * r; }
+__device__ __forceinline__ V3 normalize3(V3 v) { float r = rcp_exact(sqrt_exact(dot3(v, v))); return v * r; }
 __device__ __forceinline__ V3 mix3(V3 a, V3 b, float t) { return a + t * (b - a); }
 __device__ __forceinline__ V3 reflect3(V3 I, V3 N) { float d = dot3(N, I); return I - (2.0f * d) * N; }
 __device__ __forceinline__ V3 refract3(V3 I, V3 N, float eta) {
     float d = dot3(N, I);
     float k = 1.0f - eta * (eta * (1.0f - d * d));
     if (k < 0.0f) return mk(0.0f, 0.0f, 0.0f);
-    return eta * I - (eta * d + sqrtf(k)) * N;
+    return eta * I - (eta * d + sqrt_exact(k)) * N;
 }
 __device__ __forceinline__ V3 abs3(V3 a) { return mk(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
 
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                                 const float AIR = 1.0003f;
                                 float ri = frontFace ? m.airOverIndex : m.indexOverAir;      // AIR / n : n / AIR
                                 float cos_theta = fminf(dot3(-L.ray.d, hitNormal), 1.0f);
-                                float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                                float sin_theta = sqrt_exact(1.0f - cos_theta * cos_theta);
                                 next = (ri * sin_theta <= 1.0f) ? refract3(L.ray.d, hitNormal, ri) : reflect3(L.ray.d, hitNormal);
                                 if (trRng < 0.5f) ii--;
                             } else {

@@ -1,6 +1,6 @@
 """The short quotient sequences of csrc/exact_div.h against the compiler's correctly rounded division, on every one
 of the 2^32 fp32 inputs (raytracing_amd/exact_div_check, built with the library, runs the comparison on the GPU).
-1/x and 0.5/x must agree everywhere; a/c for launch constants c must agree wherever the residual cannot underflow:
+1/x, 0.5/x, sqrt(x) and 1/sqrt(x) must agree everywhere; a/c for launch constants c must agree wherever the residual cannot underflow:
 differences are allowed only for |a| < 2^-100, for infinite a, and in the sign of a flushed negative denormal."""
 import os
 import re
@@ -27,6 +27,8 @@ def test_short_quotients_equal_division_on_all_inputs():
             sections[cur]["runs"].append((m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))))
     assert sections["1/x"]["bad"] == 0
     assert sections["0.5/x"]["bad"] == 0
+    assert sections["sqrt(x)"]["bad"] == 0
+    assert sections["1/sqrt(x)"]["bad"] == 0
     consts = [k for k in sections if k.startswith("x/")]
     assert len(consts) >= 20
     for k in consts:
