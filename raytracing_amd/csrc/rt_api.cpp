@@ -244,7 +244,8 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
         // the reference's pre-order (a node's left child, when interior, is the next record); an interior
         // child is referenced by its record's byte offset ----
         // The first kTopRecords records are the top of the tree in breadth-first order (the nodes every ray passes),
-        // so that they are contiguous; the others follow in pre-order.
+        // so that they are contiguous; the others follow in pre-order. (Choosing them by box area instead, largest
+        // first, covers the same share of the visits: measured, no gain.)
         constexpr uint32_t kUnset = 0xffffffffu;
         std::vector<uint32_t> recordOf(nNode, kUnset);
         uint32_t nInterior = 0;
