@@ -94,7 +94,8 @@ void rt_destroy(rt_context *ctx);
  *   node8   float[8*nNode]  max.xyz, min.xyz, float(triCount), float(triStart | rightChild),
  *                           nodes in pre-order, first child = parent + 1
  *                           (u_BoundingBoxes / u_BoundingBoxesCount, Fragment.glsl:87-88,195-205)
- * The arrays are validated (indices in range, tree well-formed, depth <= 64, leaves <= 16
+ * The arrays are validated (indices in range, tree well-formed, interior nodes at most 63 levels
+ * deep with the root as level 1 -- what the shader's stack[64] can hold --, leaves <= 16
  * triangles, nTri < 2^24) and re-laid-out for the GPU; nNode == 0 gives an empty scene. */
 int rt_scene_upload(rt_context *ctx, const float *tri12, const int32_t *matIdx, uint32_t nTri,
                     const float *node8, uint32_t nNode);

@@ -17,7 +17,7 @@
 #include "rt_mi355x.h"
 
 namespace rtd {
-void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames);
+void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames, const FrameParams* single, uint32_t* queueHeads);
 void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
                  void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
                  const uint32_t* order, uint32_t* tileCost);
@@ -47,7 +47,10 @@ struct rt_context {
     MaterialRec* dMaterials = nullptr;
     void* dAccum = nullptr;          // tile-major shard, shardTiles*64 float4
     void* dLinear = nullptr;         // row-major staging image, width*height float4
-    FrameParams* dFrames = nullptr; uint32_t framesCap = 0;
+    FrameParams* dFrames = nullptr; uint32_t framesCap = 0;   // per-frame records of a multi-frame launch
+    // pinned staging for the records of multi-frame launches: a slot is reused once the copy out of it has run
+    struct FrameStage { FrameParams* host = nullptr; uint32_t cap = 0; hipEvent_t copied = nullptr; bool pending = false; };
+    FrameStage stage[4]; uint32_t stageNext = 0;
     uint32_t* dTally = nullptr;      // [kCounterSlots][maxWaves]
     void* dSpill = nullptr;          // stack spill area, maxWaves * SpillEntriesPerWave() * 8 bytes
     uint32_t* dQueue = nullptr;      // 64 words; the first 8 are the per-band tile counters
@@ -58,6 +61,8 @@ struct rt_context {
     void* dSortTemp = nullptr; size_t sortTempBytes = 0;
     bool orderValid = false;
     uint64_t launchesSinceAlloc = 0;
+    uint32_t launchesSinceReduce = 0; // the 32-bit per-wave tallies are folded into the 64-bit totals every few launches
+    uint64_t shardPixels = 0;        // pixels of this shard that lie inside the image
     uint32_t maxWaves = 0;           // persistent grid size limit (resident waves of the device)
     unsigned long long* dTotals = nullptr;   // [kCounterSlots]
     int32_t* dIds = nullptr;
@@ -97,6 +102,16 @@ int AllocShard(rt_context* c) {
     c->orderValid = false; c->launchesSinceAlloc = 0; c->sortTempBytes = 0;
     c->sp.shardTiles = ShardTiles(c);
     const uint32_t n = c->sp.shardTiles;
+    {   // pixels of this shard: tiles j*world+rank, clipped to the image
+        uint64_t px = 0;
+        const uint32_t nTiles = c->sp.tilesX * c->sp.tilesY;
+        for (uint32_t t = c->sp.shardRank; t < nTiles; t += c->sp.shardWorld) {
+            uint32_t tx = t % c->sp.tilesX, ty = t / c->sp.tilesX;
+            uint32_t w = std::min<uint32_t>(kTile, c->width - tx * kTile), h = std::min<uint32_t>(kTile, c->height - ty * kTile);
+            px += (uint64_t)w * h;
+        }
+        c->shardPixels = px;
+    }
     size_t bytes = (size_t)n * 64 * sizeof(float) * 4;
     HIP_TRY(c, hipMalloc(&c->dAccum, bytes));
     HIP_TRY(c, hipMemsetAsync(c->dAccum, 0, bytes, c->stream));
@@ -182,6 +197,8 @@ int rt_create(int device, uint32_t width, uint32_t height, rt_context** out) {
         if (me == hipSuccess) me = hipMemsetAsync(c->dTally, 0, tb, c->stream);
         if (me == hipSuccess) me = hipMalloc(&c->dSpill, (size_t)c->maxWaves * SpillEntriesPerWave() * 8);
         if (me == hipSuccess) me = hipMalloc((void**)&c->dQueue, 256);
+        if (me == hipSuccess) me = hipMalloc((void**)&c->dFrames, sizeof(FrameParams) * 64);
+        if (me == hipSuccess) c->framesCap = 64;
         if (me != hipSuccess) rc = Fail(c, RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(me));
     }
     if (rc != RT_OK) { g_globalError = c->error; rt_destroy(c); return rc; }
@@ -197,6 +214,7 @@ void rt_destroy(rt_context* c) {
     for (auto& pr : c->pendingEvents) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : c->freeEvents) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     FreePostprocess(&c->postScratch);
+    for (auto& sg : c->stage) { if (sg.host) (void)hipHostFree(sg.host); if (sg.copied) (void)hipEventDestroy(sg.copied); }
     void* ptrs[] = {c->dNodes, c->dTris, c->dNoise, c->dSky, c->dMaterials, c->dAccum, c->dLinear, c->dFrames, c->dTally, c->dTotals, c->dIds, c->dSpill, c->dQueue,
                     c->dTileCost, c->dOrderKeys, c->dOrderVals, c->dSortTemp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -204,7 +222,7 @@ void rt_destroy(rt_context* c) {
     delete c;
 }
 
-int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, uint32_t nTri, const float* node8, uint32_t nNode) {
+int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, uint32_t nTri, const float* node8, uint32_t nNode) try {
     if (!c) return RT_ERR_INVALID;
     if ((nTri && (!tri12 || !matIdx)) || (nNode && !node8)) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: NULL array");
     if (nTri >= (1u << 24)) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: %u triangles; indices travel as floats and are exact only below 2^24", nTri);
@@ -232,7 +250,10 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
                 if (in.ref < 0 || (uint64_t)in.ref + (uint64_t)in.count > nTri) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: leaf %u triangle range out of bounds", i);
             } else {
                 if (in.count < 0) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: node %u has a negative triangle count", i);
-                if (depth > kMaxStack) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: tree deeper than %d levels", kMaxStack);
+                // An interior node at depth d (root = 1) defers its far child into stack entry d when all its ancestors
+                // were entered through both children; entries 0 .. kMaxStack-1 exist (the shader's stack[64] holds the
+                // same: its interior nodes may be 63 deep).
+                if (depth >= kMaxStack) return Fail(c, RT_ERR_UNSUPPORTED, "rt_scene_upload: interior nodes more than %d levels deep", kMaxStack - 1);
                 if (in.ref <= (int)i + 1 || (uint32_t)in.ref >= nNode || i + 1 >= nNode) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: node %u has a bad right child %d", i, in.ref);
                 if (depth > maxInteriorDepth) maxInteriorDepth = depth;
                 todo.emplace_back((uint32_t)in.ref, depth + 1);
@@ -318,6 +339,8 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
     }
     c->haveScene = true;
     return RT_OK;
+} catch (const std::exception& e) {
+    return Fail(c, RT_ERR_DEVICE, "out of host memory or internal error: %s", e.what());
 }
 
 namespace {
@@ -364,7 +387,7 @@ int rt_set_bounce_limit(rt_context* c, uint32_t bl) {
     return RT_OK;
 }
 
-int rt_set_noise(rt_context* c, const uint8_t* rgb, uint32_t w, uint32_t h) {
+int rt_set_noise(rt_context* c, const uint8_t* rgb, uint32_t w, uint32_t h) try {
     if (!c) return RT_ERR_INVALID;
     if (!rgb || w == 0 || h == 0 || w > 16384 || h > 16384) return Fail(c, RT_ERR_INVALID, "rt_set_noise: bad texture");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -378,6 +401,8 @@ int rt_set_noise(rt_context* c, const uint8_t* rgb, uint32_t w, uint32_t h) {
     c->sp.noise = c->dNoise; c->sp.noiseW = (int32_t)w; c->sp.noiseH = (int32_t)h;
     c->haveNoise = true;
     return RT_OK;
+} catch (const std::exception& e) {
+    return Fail(c, RT_ERR_DEVICE, "out of host memory or internal error: %s", e.what());
 }
 
 int rt_set_skybox(rt_context* c, const uint8_t* const faces[6], uint32_t size) {
@@ -433,7 +458,7 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
     // a wave takes one 8x8 tile from its queue at a time (measured best: 8.38 ms against 8.52 with two, 9.16 with four)
     const uint32_t nGroups = c->sp.shardTiles;
     const uint32_t nWaves = std::max<uint32_t>(1u, std::min<uint32_t>(nGroups, c->maxWaves));
-    HIP_TRY(c, hipMemsetAsync(c->dQueue, 0, 256, c->stream));
+    // (the tile queue heads were cleared by prepare_frames_kernel, which UploadFrames queued just before)
     // The order is rebuilt after launches 1, 2, 4, 8 and then after every 8th: the cost of a tile changes slowly from
     // frame to frame. Only those launches tally rays per tile (one atomic per path, about 1.5 % of a launch).
     const uint64_t k = ids ? 0 : c->launchesSinceAlloc + 1;
@@ -445,6 +470,14 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
     if (!ids) {
         c->launchesSinceAlloc = k;
         if (reorderAfter) { int rc = UpdateTileOrder(c); if (rc != RT_OK) return rc; }
+        // a wave's tally column is 32 bits wide: fold the columns into the 64-bit totals before they can wrap
+        // (stream-ordered, no host wait; rt_get_counters folds what is left)
+        c->launchesSinceReduce += std::max<uint32_t>(1u, nFrames / 64u);
+        if (c->launchesSinceReduce >= 16u) {
+            LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);
+            HIP_TRY(c, hipGetLastError());
+            c->launchesSinceReduce = 0;
+        }
     }
     return RT_OK;
 }
@@ -457,33 +490,57 @@ static int CheckRenderable(rt_context* c, const char* who) {
     return RT_OK;
 }
 
-static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* seeds3) {
-    std::vector<FrameParams> fr(n);
+// The per-frame record of frame `index` with seed triple `s` (Scene::Tick's two uniforms, src/Scene.cpp:30-31); the
+// pixel jitter is filled in on the device.
+static FrameParams MakeFrame(const rt_context* c, uint32_t index, const float* s) {
     const float BLf = (float)c->sp.bounceLimit;
     auto hash = [](uint32_t x) { x ^= x >> 17; x *= 0xed5ad4bbU; x ^= x >> 11; x *= 0xac4c1b51U; x ^= x >> 15; x *= 0x31848babU; x ^= x >> 14; return x; };
     auto hashf = [&](float f) { uint32_t u; std::memcpy(&u, &f, 4); return hash(u); };
-    for (uint32_t k = 0; k < n; ++k) {
-        const float* s = seeds3 + 3 * (size_t)k;
-        FrameParams& f = fr[k];
-        f.frameIndex = first + k;
-        f.seedY = s[1]; f.seedZ = s[2];
-        // Fragment.glsl:392-393, the terms that do not change within a frame
-        f.hashX = hash(0u) + hash(f.frameIndex) + hashf(Flush(Flush(s[0]) * BLf));
-        f.hashY = hash(0u) + hashf(Flush(Flush(s[1]) * BLf));
-        f.weight = 1.0f / (float)(f.frameIndex + 1u);     // Fragment.glsl:487
-        f.jitterX = f.jitterY = 0.0f;                     // filled in on the device below
+    FrameParams f;
+    f.frameIndex = index;
+    f.seedY = s[1]; f.seedZ = s[2];
+    // Fragment.glsl:392-393, the terms that do not change within a frame
+    f.hashX = hash(0u) + hash(f.frameIndex) + hashf(Flush(Flush(s[0]) * BLf));
+    f.hashY = hash(0u) + hashf(Flush(Flush(s[1]) * BLf));
+    f.weight = 1.0f / (float)(f.frameIndex + 1u);     // Fragment.glsl:487
+    f.jitterX = f.jitterY = 0.0f;
+    return f;
+}
+
+// Hands the frame records of a launch to the device without waiting for it, and queues prepare_frames_kernel, which
+// fills in their jitter and clears the tile queue heads. One frame: the record is an argument of that kernel.
+// Several frames: the records go through a pinned staging slot and one asynchronous copy; the host only waits when
+// all staging slots still have their copy queued, i.e. when it is four multi-frame launches ahead of the device.
+static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* seeds3) {
+    if (n == 1 && c->framesCap >= 1) {
+        const FrameParams f = MakeFrame(c, first, seeds3);
+        LaunchPrepareFrames(c->stream, c->sp, c->dFrames, 1, &f, c->dQueue);
+        HIP_TRY(c, hipGetLastError());
+        return RT_OK;
     }
     if (n > c->framesCap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->dFrames) (void)hipFree(c->dFrames);
         c->dFrames = nullptr; c->framesCap = 0;
-        HIP_TRY(c, hipMalloc((void**)&c->dFrames, sizeof(FrameParams) * n));
-        c->framesCap = n;
+        const uint32_t cap = std::max<uint32_t>(n, 64u);
+        HIP_TRY(c, hipMalloc((void**)&c->dFrames, sizeof(FrameParams) * cap));
+        c->framesCap = cap;
     }
-    // pageable source: the copy is staged before the call returns, so `fr` may go out of scope
-    HIP_TRY(c, hipMemcpyAsync(c->dFrames, fr.data(), sizeof(FrameParams) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    LaunchPrepareFrames(c->stream, c->sp, c->dFrames, n);
+    rt_context::FrameStage& sg = c->stage[c->stageNext++ % 4u];
+    if (sg.pending) { HIP_TRY(c, hipEventSynchronize(sg.copied)); sg.pending = false; }
+    if (!sg.copied) HIP_TRY(c, hipEventCreateWithFlags(&sg.copied, hipEventDisableTiming));
+    if (n > sg.cap) {
+        if (sg.host) (void)hipHostFree(sg.host);
+        sg.host = nullptr; sg.cap = 0;
+        uint32_t cap = 64; while (cap < n) cap *= 2u;
+        HIP_TRY(c, hipHostMalloc((void**)&sg.host, sizeof(FrameParams) * cap, hipHostMallocDefault));
+        sg.cap = cap;
+    }
+    for (uint32_t k = 0; k < n; ++k) sg.host[k] = MakeFrame(c, first + k, seeds3 + 3 * (size_t)k);
+    HIP_TRY(c, hipMemcpyAsync(c->dFrames, sg.host, sizeof(FrameParams) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(sg.copied, c->stream));
+    sg.pending = true;
+    LaunchPrepareFrames(c->stream, c->sp, c->dFrames, n, nullptr, c->dQueue);
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
 }
@@ -505,17 +562,7 @@ int rt_render(rt_context* c, uint32_t firstFrameIndex, uint32_t nFrames, const f
     if (rc != RT_OK) return rc;
     HIP_TRY(c, hipEventRecord(ev.second, c->stream));
     c->pendingEvents.push_back(ev);
-    if (!c->countAll) {
-        // pixels of this shard: tiles j*world+rank, clipped to the image
-        uint64_t px = 0;
-        const uint32_t nTiles = c->sp.tilesX * c->sp.tilesY;
-        for (uint32_t t = c->sp.shardRank; t < nTiles; t += c->sp.shardWorld) {
-            uint32_t tx = t % c->sp.tilesX, ty = t / c->sp.tilesX;
-            uint32_t w = std::min<uint32_t>(kTile, c->width - tx * kTile), h = std::min<uint32_t>(kTile, c->height - ty * kTile);
-            px += (uint64_t)w * h;
-        }
-        c->hostPaths += px * nFrames;
-    }
+    if (!c->countAll) c->hostPaths += c->shardPixels * nFrames;
     if (c->pendingEvents.size() > 256) { rc = ResolveEvents(c); if (rc != RT_OK) return rc; }
     return RT_OK;
 }
@@ -527,7 +574,7 @@ int rt_sync(rt_context* c) {
     return RT_OK;
 }
 
-int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) {
+int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) try {
     if (!c || !seed3 || !out3) return c ? Fail(c, RT_ERR_INVALID, "rt_primary_ids: NULL argument") : RT_ERR_INVALID;
     if (c->sp.shardWorld != 1) return Fail(c, RT_ERR_STATE, "rt_primary_ids: only on an unsharded context");
     int rc = CheckRenderable(c, "rt_primary_ids");
@@ -535,6 +582,10 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) {
     HIP_TRY(c, hipSetDevice(c->device));
     rc = UploadFrames(c, 0, 1, seed3);
     if (rc != RT_OK) return rc;
+    // what rt_render has tallied so far goes to the totals first: the id pass shares the tally columns
+    LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);
+    HIP_TRY(c, hipGetLastError());
+    c->launchesSinceReduce = 0;
     const size_t n = (size_t)c->sp.shardTiles * 64;
     if (!c->dIds) HIP_TRY(c, hipMalloc((void**)&c->dIds, n * 3 * sizeof(int32_t)));
     HIP_TRY(c, hipMemsetAsync(c->dIds, 0xff, n * 3 * sizeof(int32_t), c->stream));
@@ -548,9 +599,11 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) {
             size_t slot = ((size_t)(y / kTile) * c->sp.tilesX + x / kTile) * 64 + (y % kTile) * kTile + x % kTile;
             std::memcpy(out3 + ((size_t)y * c->width + x) * 3, tiled.data() + slot * 3, 3 * sizeof(int32_t));
         }
-    // the id pass also ran the tallies; drop them so that counters describe rt_render only
+    // the id pass ran the tallies too; drop its own so that the counters describe rt_render only
     HIP_TRY(c, hipMemsetAsync(c->dTally, 0, (size_t)kCounterSlots * c->maxWaves * sizeof(uint32_t), c->stream));
     return RT_OK;
+} catch (const std::exception& e) {
+    return Fail(c, RT_ERR_DEVICE, "out of host memory or internal error: %s", e.what());
 }
 
 int rt_postprocess(rt_context* c, int bloom_on, float* rgba_out, uint8_t* rgb8_out) {

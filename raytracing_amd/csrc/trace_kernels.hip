@@ -446,15 +446,20 @@ __device__ __forceinline__ void leaf_step(const SceneParams& sp, const StackRef&
     pop_next<COUNT, ITERS>(st, L);
 }
 
-// Fills in the per-frame pixel jitter (F:461: the noise lookup there depends on the frame's seed
-// only, so it is done once per frame here instead of once per pixel).
-__global__ void prepare_frames_kernel(SceneParams sp, FrameParams* __restrict__ frames, uint32_t nFrames) {
+// Runs before every launch of the tracer, on the same stream: fills in the per-frame pixel jitter (F:461: the noise
+// lookup there depends on the frame's seed only, so it is done once per frame here instead of once per pixel) and
+// clears the tile queue heads. A one-frame launch hands its record over as a kernel argument (`single`), so that
+// the host neither copies nor waits; the records of a multi-frame launch are already in `frames`.
+__global__ void prepare_frames_kernel(SceneParams sp, FrameParams* __restrict__ frames, uint32_t nFrames, FrameParams single, int useSingle,
+                                      uint32_t* __restrict__ queueHeads /* [64] */) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < 64u) queueHeads[k] = 0u;
     if (k >= nFrames) return;
-    FrameParams f = frames[k];
+    FrameParams f = useSingle ? single : frames[k];
     V3 ro = sample_noise(sp, f.seedY + 0.007f * 0.0f, f.seedZ + 0.007f * 0.0f);
-    frames[k].jitterX = ro.x;
-    frames[k].jitterY = ro.y;
+    f.jitterX = ro.x;
+    f.jitterY = ro.y;
+    frames[k] = f;
 }
 
 // COUNT: full tallies; IDS: primary-hit ids instead of radiance (one frame); SINGLE: the launch
@@ -836,8 +841,9 @@ uint32_t ResidentWaves() {
     return (uint32_t)cus * (uint32_t)perCu * (uint32_t)kWgWaves;
 }
 
-void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames) {
-    hipLaunchKernelGGL(prepare_frames_kernel, dim3((nFrames + 63u) / 64u), dim3(64), 0, st, sp, frames, nFrames);
+void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames, const FrameParams* single, uint32_t* queueHeads) {
+    hipLaunchKernelGGL(prepare_frames_kernel, dim3((nFrames + 63u) / 64u), dim3(64), 0, st, sp, frames, nFrames, single ? *single : FrameParams{},
+                       single ? 1 : 0, queueHeads);
 }
 
 void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,

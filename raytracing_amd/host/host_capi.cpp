@@ -1,10 +1,20 @@
 // C ABI over the host scene model (declared in include/rt_host.h).
 #include "rt_host.h"
 
+#include <new>
 #include <string>
 #include <vector>
 
 #include "scene_data.h"
+
+// Nothing may throw across the C boundary: allocation failures and whatever else the C++ below raises
+// (std::system_error from the builder's threads, std::length_error ...) become status codes.
+template <class F>
+static int Guarded(F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { return RT_ERR_DEVICE; }      // out of memory
+    catch (...) { return RT_ERR_INVALID; }
+}
 
 struct rth_scene {
     rta::SceneData data;
@@ -45,26 +55,32 @@ extern "C" {
 
 int rth_scene_load(const char* const* paths, uint32_t nPaths, int buildThreads, rth_scene** out) {
     if (!out || (nPaths && !paths)) return RT_ERR_INVALID;
-    std::vector<std::string> p;
-    for (uint32_t i = 0; i < nPaths; ++i) p.emplace_back(paths[i] ? paths[i] : "");
-    *out = Wrap(rta::LoadScene(p, buildThreads));
-    return RT_OK;
+    *out = nullptr;
+    return Guarded([&] {
+        std::vector<std::string> p;
+        for (uint32_t i = 0; i < nPaths; ++i) p.emplace_back(paths[i] ? paths[i] : "");
+        *out = Wrap(rta::LoadScene(p, buildThreads));
+        return (int)RT_OK;
+    });
 }
 
 int rth_scene_build(const float* tri9, const int32_t* matSlot, uint32_t nTri, const rt_material* materials,
                     uint32_t nMaterials, int buildThreads, int maxLeaf, rth_scene** out) {
     if (!out || (nTri && (!tri9 || !matSlot)) || (nMaterials && !materials)) return RT_ERR_INVALID;
-    std::vector<rta::Triangle> tris;
-    tris.reserve(nTri);
-    for (uint32_t i = 0; i < nTri; ++i) {
-        const float* p = tri9 + (size_t)i * 9;
-        tris.emplace_back(rta::Vec3(p[0], p[1], p[2]), rta::Vec3(p[3], p[4], p[5]), rta::Vec3(p[6], p[7], p[8]), matSlot[i]);
-    }
-    std::vector<rta::Material> mats;
-    for (uint32_t i = 0; i < nMaterials; ++i) mats.push_back(FromAbi(materials[i]));
-    *out = Wrap(rta::BuildScene(std::move(tris), std::move(mats), buildThreads,
-                                maxLeaf > 0 ? maxLeaf : rta::BvhTree::kDefaultLeafTriangles));
-    return RT_OK;
+    *out = nullptr;
+    return Guarded([&] {
+        std::vector<rta::Triangle> tris;
+        tris.reserve(nTri);
+        for (uint32_t i = 0; i < nTri; ++i) {
+            const float* p = tri9 + (size_t)i * 9;
+            tris.emplace_back(rta::Vec3(p[0], p[1], p[2]), rta::Vec3(p[3], p[4], p[5]), rta::Vec3(p[6], p[7], p[8]), matSlot[i]);
+        }
+        std::vector<rta::Material> mats;
+        for (uint32_t i = 0; i < nMaterials; ++i) mats.push_back(FromAbi(materials[i]));
+        *out = Wrap(rta::BuildScene(std::move(tris), std::move(mats), buildThreads,
+                                    maxLeaf > 0 ? maxLeaf : rta::BvhTree::kDefaultLeafTriangles));
+        return (int)RT_OK;
+    });
 }
 
 void rth_scene_free(rth_scene* s) { delete s; }
@@ -85,11 +101,13 @@ const char* rth_scene_warning(const rth_scene* s, uint32_t i) { return i < s->da
 
 int rth_scene_send(const rth_scene* s, rt_context* ctx) {
     if (!s || !ctx) return RT_ERR_INVALID;
-    int rc = rt_scene_upload(ctx, s->data.tri12.data(), s->data.matIdx.data(), s->data.TriangleCount(),
-                             s->data.node8.data(), s->data.NodeCount());
-    if (rc != RT_OK) return rc;
-    uint32_t n = (uint32_t)s->mats.size();
-    return rt_set_materials(ctx, s->mats.data(), n > 16 ? 16 : n);
+    return Guarded([&] {
+        int rc = rt_scene_upload(ctx, s->data.tri12.data(), s->data.matIdx.data(), s->data.TriangleCount(),
+                                 s->data.node8.data(), s->data.NodeCount());
+        if (rc != RT_OK) return rc;
+        uint32_t n = (uint32_t)s->mats.size();
+        return rt_set_materials(ctx, s->mats.data(), n > 16 ? 16 : n);
+    });
 }
 
 }  // extern "C"
@@ -142,35 +160,42 @@ int rth_ini_object_paths(const char* iniPath, char* buf, uint32_t bufSize, char*
     }
 }
 int rth_write_png_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* rgb, int flip) {
-    return rta::WritePngRgb8(path, w, h, rgb, flip != 0) ? RT_OK : RT_ERR_INVALID;
+    if (!path || !rgb) return RT_ERR_INVALID;
+    return Guarded([&] { return rta::WritePngRgb8(path, w, h, rgb, flip != 0) ? (int)RT_OK : (int)RT_ERR_INVALID; });
 }
 
 int rth_read_png(const char* path, int channels, uint32_t* width, uint32_t* height, uint8_t* pixels, uint64_t capacity) {
-    rta::Image8 img;
-    if (!path || !rta::LoadPng(path, channels, img)) return RT_ERR_INVALID;
-    if (width) *width = img.width;
-    if (height) *height = img.height;
-    if (pixels) {
-        if (capacity < img.pixels.size()) return RT_ERR_INVALID;
-        std::memcpy(pixels, img.pixels.data(), img.pixels.size());
-    }
-    return RT_OK;
+    if (!path) return RT_ERR_INVALID;
+    return Guarded([&] {
+        rta::Image8 img;
+        if (!rta::LoadPng(path, channels, img)) return (int)RT_ERR_INVALID;
+        if (width) *width = img.width;
+        if (height) *height = img.height;
+        if (pixels) {
+            if (capacity < img.pixels.size()) return (int)RT_ERR_INVALID;
+            std::memcpy(pixels, img.pixels.data(), img.pixels.size());
+        }
+        return (int)RT_OK;
+    });
 }
 
 int rth_app_create(rt_context* ctx, uint32_t w, uint32_t h, rth_app** out) {
     if (!ctx || !out) return RT_ERR_INVALID;
-    *out = new rth_app(ctx, w, h);
-    return RT_OK;
+    *out = nullptr;
+    return Guarded([&] { *out = new rth_app(ctx, w, h); return (int)RT_OK; });
 }
 void rth_app_destroy(rth_app* a) { delete a; }
 int rth_app_load_objects(rth_app* a, const char* const* paths, uint32_t n, int threads) {
-    std::vector<std::string> p;
-    for (uint32_t i = 0; i < n; ++i) p.emplace_back(paths[i]);
-    return a->app.LoadObjects(p, threads);
+    if (!a || (n && !paths)) return RT_ERR_INVALID;
+    return Guarded([&] {
+        std::vector<std::string> p;
+        for (uint32_t i = 0; i < n; ++i) p.emplace_back(paths[i] ? paths[i] : "");
+        return a->app.LoadObjects(p, threads);
+    });
 }
 void rth_app_key(rth_app* a, int key, int action) { a->app.OnKey(key, action); }
-int rth_app_tick(rth_app* a) { return a->app.Tick(); }
-int rth_app_read_display(rth_app* a, float* rgba, uint8_t* rgb8) { return a->app.ReadDisplay(rgba, rgb8); }
+int rth_app_tick(rth_app* a) { return a ? Guarded([&] { return a->app.Tick(); }) : (int)RT_ERR_INVALID; }
+int rth_app_read_display(rth_app* a, float* rgba, uint8_t* rgb8) { return a ? Guarded([&] { return a->app.ReadDisplay(rgba, rgb8); }) : (int)RT_ERR_INVALID; }
 void rth_app_get_state(const rth_app* a, rth_app_state* o) {
     rta::HeadlessApp& app = const_cast<rth_app*>(a)->app;
     FillCamera(app.GetCamera(), o->camera);
@@ -191,7 +216,13 @@ void rth_app_configure(rth_app* a, int bloom, int postEveryFrame, uint32_t frame
 void rth_app_push_pose(rth_app* a, const float* p, const float* f) {
     a->app.GetRecorder().PushPose(rta::Pose{{p[0], p[1], p[2]}, {f[0], f[1], f[2]}});
 }
-int rth_app_save_poses(const rth_app* a, const char* path) { return const_cast<rth_app*>(a)->app.GetRecorder().SavePoses(path) ? RT_OK : RT_ERR_INVALID; }
-int rth_app_load_poses(rth_app* a, const char* path) { return a->app.GetRecorder().LoadPoses(path) ? RT_OK : RT_ERR_INVALID; }
+int rth_app_save_poses(const rth_app* a, const char* path) {
+    if (!a || !path) return RT_ERR_INVALID;
+    return Guarded([&] { return const_cast<rth_app*>(a)->app.GetRecorder().SavePoses(path) ? (int)RT_OK : (int)RT_ERR_INVALID; });
+}
+int rth_app_load_poses(rth_app* a, const char* path) {
+    if (!a || !path) return RT_ERR_INVALID;
+    return Guarded([&] { return a->app.GetRecorder().LoadPoses(path) ? (int)RT_OK : (int)RT_ERR_INVALID; });
+}
 
 }  // extern "C"

@@ -18,6 +18,8 @@ int Paeth(int a, int b, int c) {
 
 bool Fail(std::string* e, const char* msg) { if (e) *e = msg; return false; }
 
+constexpr uint32_t kMaxPngSide = 16384;
+
 }  // namespace
 
 bool LoadPng(const std::string& path, int want, Image8& out, std::string* error) {
@@ -49,6 +51,9 @@ bool LoadPng(const std::string& path, int want, Image8& out, std::string* error)
     }
     const bool packed = depth < 8 && (colour == 0 || colour == 3) && (depth == 1 || depth == 2 || depth == 4);
     if (!w || !h || (depth != 8 && !packed) || interlace != 0) return Fail(error, "unsupported PNG (need up to 8 bits per sample, non-interlaced)");
+    // the header is untrusted: bound the allocations below (the renderer takes textures up to 16384 texels a side)
+    if (w > kMaxPngSide || h > kMaxPngSide) return Fail(error, "image larger than 16384 x 16384");
+    if (idat.empty()) return Fail(error, "no image data");
     int src = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : colour == 6 ? 4 : 0;
     if (!src) return Fail(error, "unsupported colour type");
     const size_t stride = packed ? ((size_t)w * depth + 7) / 8 : (size_t)w * src;

@@ -23,13 +23,32 @@ public:
         out.assign(b, p_);
         return true;
     }
+    // Accepts what `istream >> float` accepts: an optional sign, decimal digits with an optional point, an optional
+    // decimal exponent. strtof alone would also take "nan", "inf" and hexadecimal floats, which the reference's
+    // stream extraction (Include/ObjectLoader.h:137-139) rejects or cuts short.
     bool Float(float& out) {
         if (failed_) return false;
         Skip();
+        const char* q = p_;
+        if (*q == '+' || *q == '-') ++q;
+        const char* digits = q;
+        while (*q >= '0' && *q <= '9') ++q;
+        if (*q == '.') { ++q; while (*q >= '0' && *q <= '9') ++q; }
+        if (q == digits || (q == digits + 1 && *digits == '.')) { failed_ = true; return false; }
+        if (*q == 'e' || *q == 'E') {
+            const char* e = q + 1;
+            if (*e == '+' || *e == '-') ++e;
+            if (*e >= '0' && *e <= '9') { while (*e >= '0' && *e <= '9') ++e; q = e; }
+        }
         char* end = nullptr;
         float v = std::strtof(p_, &end);
-        if (end == p_) { failed_ = true; return false; }
-        p_ = end; out = v;
+        if (end != q) {
+            // strtof read on past the decimal syntax (a hexadecimal float): convert the decimal prefix alone
+            std::string prefix(p_, q);
+            v = std::strtof(prefix.c_str(), &end);
+            if (end == prefix.c_str()) { failed_ = true; return false; }
+        }
+        p_ = q; out = v;
         return true;
     }
     bool Int(int& out) {

@@ -1,0 +1,93 @@
+"""rt_render only queues work: it returns while the frame is still being traced, frames queued back to back give
+the same image as frames rendered one by one with a wait in between, and the counters survive an id pass."""
+import time
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from raytracing_amd import scenes
+from util import differing_pixels, make_scene, setup
+
+pytestmark = pytest.mark.gpu
+
+NOISE, SKY = scenes.noise_texture(64, 48), scenes.sky_cubemap(32)
+
+
+def test_render_returns_while_the_frame_is_still_running():
+    W, H = 3840, 2160
+    sc = make_scene("sponza_like", target_tris=20000)
+    seeds = scenes.frame_seeds(40)
+    g = ra.Renderer(W, H)
+    setup(g, sc, NOISE, SKY, bounce_limit=8)
+    for k in range(8):                       # warm-up: code object, and the launches that re-sort the tile order
+        g.render(k, seeds[k:k + 1])
+    g.sync()
+    t0 = time.perf_counter()
+    g.render(8, seeds[8:9])
+    g.sync()
+    frame = time.perf_counter() - t0         # one 4K frame, start to finish
+    calls = []
+    for k in range(9, 15):                   # launches 10..15: none of them re-sorts the tile order
+        t0 = time.perf_counter()
+        g.render(k, seeds[k:k + 1])
+        calls.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    g.sync()
+    drain = time.perf_counter() - t0
+    assert frame > 1e-3, "a 4K frame takes milliseconds"
+    assert sorted(calls)[len(calls) // 2] < 100e-6, "rt_render must only queue work: median call took %.0f us" % (1e6 * sorted(calls)[len(calls) // 2])
+    assert max(calls) < frame / 4, calls
+    assert drain > 2 * frame, "the queued frames must still have been running when the calls returned"
+    queued = g.read_accum()
+    g.clear()
+    for k in range(15):
+        g.render(k, seeds[k:k + 1])
+        g.sync()
+    assert differing_pixels(queued, g.read_accum()) == 0
+    g.close()
+
+
+def test_multi_frame_launches_queue_without_waiting_and_keep_their_seeds():
+    """Several multi-frame launches in flight: each one's frame records travel through a staging slot of their own."""
+    W, H = 640, 360
+    sc = make_scene("sponza_like", target_tris=20000)
+    seeds = scenes.frame_seeds(6 * 5)
+    g = ra.Renderer(W, H)
+    setup(g, sc, NOISE, SKY, bounce_limit=4)
+    for j in range(6):                        # more launches than staging slots
+        g.render(5 * j, seeds[5 * j:5 * j + 5])
+    queued = g.read_accum()
+    g.clear()
+    for k in range(30):
+        g.render(k, seeds[k:k + 1])
+        g.sync()
+    assert differing_pixels(queued, g.read_accum()) == 0
+    g.close()
+
+
+def test_counters_survive_an_id_pass_and_many_launches():
+    W, H = 160, 96
+    sc = make_scene("sponza_like", target_tris=20000)
+    seeds = scenes.frame_seeds(40)
+    g = ra.Renderer(W, H)
+    setup(g, sc, NOISE, SKY, bounce_limit=4)
+    g.counters(reset=True)
+    g.render(0, seeds[:3])
+    g.primary_ids(seeds[0])                   # shares the tally columns with rt_render
+    c = g.counters()
+    assert c["paths"] == 3 * W * H and c["rays"] >= c["paths"]
+    rays3 = c["rays"]
+    # the per-wave tallies are folded into 64-bit totals every few launches; nothing may be lost or counted twice
+    one = ra.Renderer(W, H)
+    setup(one, sc, NOISE, SKY, bounce_limit=4)
+    one.render(0, seeds)
+    want = one.counters()
+    g.clear()
+    g.counters(reset=True)
+    for k in range(40):
+        g.render(k, seeds[k:k + 1])
+    got = g.counters()
+    assert got["rays"] == want["rays"] and got["paths"] == want["paths"] == 40 * W * H
+    assert rays3 > 0
+    g.close(); one.close()

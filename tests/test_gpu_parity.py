@@ -262,3 +262,58 @@ def test_deep_stack_spills_to_memory_bit_exact():
     assert differing_pixels(g.read_accum(), o.read_accum()) == 0
     assert (g.primary_ids(SEEDS[0]) == o.primary_ids(SEEDS[0])).all()
     g.close()
+
+
+def _chain_scene(levels):
+    """A hand-built tree that is one chain of `levels` interior nodes: every interior node's left child is the next
+    interior node (the last one's is a leaf), its right child a leaf. All boxes overlap along the view axis and the
+    interior boxes start nearer than the leaf boxes, so a ray enters the left child first and defers the right one at
+    every level: the deferred-node stack grows to `levels` entries. The leaves' triangles come nearer the further up
+    their leaf hangs, so every deferred leaf is still worth visiting when it is popped."""
+    n_leaf = levels + 1
+    n_node = 2 * levels + 1
+    node8 = np.zeros((n_node, 8), dtype=np.float32)
+    tri12 = np.zeros((n_leaf, 12), dtype=np.float32)
+    # pre-order: interior 1..levels at indices 0..levels-1, then the deepest left leaf, then the right leaves from the
+    # deepest interior node upwards
+    def tri_at(x):
+        return [x, -40, -40, 0, x, 40, -40, 0, x, 0, 40, 0]
+    xs = 60.0 - 0.5 * np.arange(n_leaf)             # leaf j (in visiting order) holds a triangle at x = xs[j]
+    for j in range(n_leaf):
+        tri12[j] = tri_at(xs[j])
+        node = levels + j
+        node8[node] = [xs[j] + 0.25, 50, 50, xs[j] - 0.25, -50, -50, 1, j]
+    for k in range(levels):                          # interior node at depth k + 1
+        right = levels + (levels - k)                # its right leaf: visited (levels - k)-th after the left-most leaf
+        node8[k] = [100, 50, 50, 1, -50, -50, 0, right]
+    return tri12, np.zeros(n_leaf, np.int32), node8
+
+
+def test_deepest_tree_the_stack_can_hold_bit_exact():
+    """Interior nodes 63 levels deep, every ray entering both children of each: what the shader's stack[64] can just
+    hold (Fragment.glsl:9,270). One level more is refused at upload."""
+    tri12, matidx, node8 = _chain_scene(63)
+    mats = np.array([[0.8, 0.6, 0.3, 1, 1, 1, 1, 0, 0, 0, 0]], dtype=np.float32)
+    W, H = 64, 40
+    camera = dict(DEFAULT_CAMERA, viewport_width=0.5)
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    for r in (g, o):
+        r.set_scene(tri12, matidx, node8)
+        r.set_materials(mats)
+        r.set_camera(**camera)
+        r.set_noise(NOISE)
+        r.set_skybox(SKY)
+        r.set_bounce_limit(4)
+    a, b = g.primary_ids(SEEDS[0]), o.primary_ids(SEEDS[0])
+    assert (a == b).all()
+    assert (a[..., 0] == 63).all(), "every primary ray must end on the last leaf visited"
+    assert (a[..., 2] >= 2 * 63).all(), "every level's deferred leaf must have been popped and visited"
+    for r in (g, o):
+        r.render(0, SEEDS[:2])
+    assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+    # a second, sharded context renders next to it: with a stack entry too many, one wave's deepest entries would
+    # land in its neighbour's spill rows
+    deeper = _chain_scene(64)
+    with pytest.raises(ra.RtError, match="63"):
+        g.set_scene(*deeper)
+    g.close()

@@ -1,0 +1,60 @@
+"""Hostile or odd inputs to the host-side file readers end in an error code, never in an exception, an abort or a
+giant allocation, and numbers are read the way the reference's `istream >> float` reads them
+(Include/ObjectLoader.h:137-139): decimal only."""
+import ctypes
+import struct
+import zlib
+
+import raytracing_amd as ra
+from raytracing_amd import _lib
+
+HEADER = "lambertian 0.5 0.5 0.5\n"
+TRI = "0 0 0  1 0 0  0 1 0\n"
+
+
+def load(tmp_path, body, name="obj.txt"):
+    p = tmp_path / name
+    p.write_text(body)
+    return ra.load_scene([str(p)])
+
+
+def test_plain_decimal_forms_are_read(tmp_path):
+    sc = load(tmp_path, HEADER + "1\n+1.5 -.25 3.  1e1 2.5E-1 -1e+0  7 8 9\n")
+    assert sc.n_triangles == 1
+    assert list(sc.tri12[:3]) == [1.5, -0.25, 3.0] and list(sc.tri12[4:7]) == [10.0, 0.25, -1.0]
+
+
+def test_nan_inf_and_words_are_rejected_like_stream_extraction(tmp_path):
+    for bad in ("nan", "inf", "-inf", "NaN", "infinity", "abc", ".", "-"):
+        sc = load(tmp_path, HEADER + "2\n" + TRI + "0 0 %s  1 0 0  0 1 0\n" % bad)
+        assert sc.n_triangles == 0 and sc.warnings, bad        # the file fails as a whole (Scene.cpp:97-111 skips it)
+
+
+def test_hexadecimal_float_stops_after_its_leading_zero(tmp_path):
+    # `istream >> float` reads "0" from "0x10" and leaves "x10", on which the next extraction fails
+    sc = load(tmp_path, HEADER + "1\n0x10 0 0  1 0 0  0 1 0\n")
+    assert sc.n_triangles == 0 and sc.warnings
+
+
+def png_with_header(width, height, idat=b""):
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 2, 0, 0, 0))
+    if idat is not None:
+        out += chunk(b"IDAT", idat)
+    return out + chunk(b"IEND", b"")
+
+
+def test_png_with_a_hostile_header_is_refused_without_allocating(tmp_path):
+    L = _lib.lib()
+    w, h = ctypes.c_uint32(), ctypes.c_uint32()
+    for name, data in (("huge.png", png_with_header(0xFFFFFFFF, 0xFFFFFFFF, zlib.compress(b"\0" * 16))),
+                       ("wide.png", png_with_header(1 << 20, 4, zlib.compress(b"\0" * 16))),
+                       ("nodata.png", png_with_header(4, 4, None)),
+                       ("short.png", png_with_header(4, 4, zlib.compress(b"\0" * 5)))):
+        p = tmp_path / name
+        p.write_bytes(data)
+        assert L.rth_read_png(str(p).encode(), 3, ctypes.byref(w), ctypes.byref(h), None, 0) == -1, name
+    good = tmp_path / "good.png"
+    good.write_bytes(png_with_header(2, 2, zlib.compress((b"\0" + b"\x10\x20\x30" * 2) * 2)))
+    assert L.rth_read_png(str(good).encode(), 3, ctypes.byref(w), ctypes.byref(h), None, 0) == 0 and (w.value, h.value) == (2, 2)
