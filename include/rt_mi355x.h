@@ -140,6 +140,23 @@ int rt_primary_ids(rt_context *ctx, const float *seed3, int32_t *out3);
  * Recorder::WriteTexture reads back (Include/Recorder.h:93-100). */
 int rt_postprocess(rt_context *ctx, int bloom_on, float *rgba_out, uint8_t *rgb8_out);
 
+/* The bloom chain + final composite as one call that allocates nothing. It has no counterpart in the reference; it
+ * is for callers that cannot allocate device memory while they run: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc. Same kernels and same results as
+ *     rt_display_reset(ctx); rt_accum_write(ctx, accum); rt_postprocess(ctx, 1, rgba, rgb8);
+ * but every image is DEVICE memory of the current HIP device: accumDevice = width*height RGBA floats, rows bottom-up
+ * (what rt_accum_read returns); rgbaOutDevice (width*height*4 floats) and rgb8OutDevice (width*height*3 bytes)
+ * receive the composite, either may be NULL. The work is queued on hipStream (a hipStream_t, NULL = the default
+ * stream); the call does not wait for it. The chain's working images live in one fixed 20 MiB array in device
+ * memory that every GPU the library runs on holds until the process ends: images up to 3840x2160 fit, larger ones
+ * are refused with RT_ERR_UNSUPPORTED (message: rt_last_global_error). Nothing is carried over from call to call
+ * (each call starts from a cleared tmp texture, like the first frame of a fresh process). All calls on one GPU share
+ * that array: calls that overlap in time on one GPU race; order them on one stream or with events. The array's
+ * address is looked up once per device, by rt_create or by the first call on that device; make that first call
+ * (or any rt_create) outside graph capture. */
+int rt_postprocess_static(const float *accumDevice, uint32_t width, uint32_t height, float *rgbaOutDevice,
+                          uint8_t *rgb8OutDevice, void *hipStream);
+
 /* Reads the image the last rt_postprocess(bloom_on = 1) left on display (the reference's tmp
  * texture) without running the chain again. */
 int rt_display_read(rt_context *ctx, float *rgba_out, uint8_t *rgb8_out);

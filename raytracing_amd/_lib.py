@@ -58,6 +58,7 @@ SIGNATURES = {
     "rt_sync": (I, [P]),
     "rt_primary_ids": (I, [P, P, P]),
     "rt_postprocess": (I, [P, I, P, P]),
+    "rt_postprocess_static": (I, [P, U32, U32, P, P, P]),
     "rt_display_read": (I, [P, P, P]),
     "rt_display_reset": (I, [P]),
     "rt_get_counters": (I, [P, ctypes.POINTER(rt_counters), I]),

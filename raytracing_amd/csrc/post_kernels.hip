@@ -38,21 +38,22 @@ struct AccumView {
     }
 };
 
-__global__ void down_kernel(AccumView accum, float4* __restrict__ tmp, int W, int H, int w, int h) {
+// (S = row stride of tmp and pre, in texels: the window width when they are whole-window images)
+__global__ void down_kernel(AccumView accum, float4* __restrict__ tmp, int S, int W, int H, int w, int h) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
     int sx = (int)floorf(((float)x + 0.5f) * ((float)W / (float)w));
     int sy = (int)floorf(((float)y + 0.5f) * ((float)H / (float)h));
     sx = min(sx, W - 1); sy = min(sy, H - 1);
     float4 s = accum.at(sx, sy);
-    tmp[(size_t)y * W + x] = make_float4(s.x, s.y, s.z, 0.0f);
+    tmp[(size_t)y * S + x] = make_float4(s.x, s.y, s.z, 0.0f);
 }
 
 // E:9-16 then B:9-18 and the texel-only factors of B:35: out = (cc(rgb) * level) * 0.5, w = level >= 1.01
-__global__ void pre_kernel(const float4* __restrict__ tmp, float4* __restrict__ pre, int W, int rw, int rh) {
+__global__ void pre_kernel(const float4* __restrict__ tmp, float4* __restrict__ pre, int S, int rw, int rh) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= rw || y >= rh) return;
-    float4 s = tmp[(size_t)y * W + x];
+    float4 s = tmp[(size_t)y * S + x];
     float len = sqrtf((s.z * s.z + s.y * s.y) + s.x * s.x);
     float c[3] = {0.0f, 0.0f, 0.0f};
     if (len >= 1.5f) { c[0] = s.x; c[1] = s.y; c[2] = s.z; }
@@ -61,7 +62,7 @@ __global__ void pre_kernel(const float4* __restrict__ tmp, float4* __restrict__ 
         float e = 1.0f / level;
         for (int k = 0; k < 3; ++k) c[k] = powf(c[k] / level, e);
     }
-    pre[(size_t)y * W + x] = make_float4((c[0] * level) * 0.5f, (c[1] * level) * 0.5f, (c[2] * level) * 0.5f, level >= 1.01f ? 1.0f : 0.0f);
+    pre[(size_t)y * S + x] = make_float4((c[0] * level) * 0.5f, (c[1] * level) * 0.5f, (c[2] * level) * 0.5f, level >= 1.01f ? 1.0f : 0.0f);
 }
 
 constexpr int kBlurTX = 32, kBlurTY = 8, kApron = 4;
@@ -69,7 +70,7 @@ constexpr int kTileW = kBlurTX + 2 * kApron, kTileH = kBlurTY + 2 * kApron;
 
 // B:20-46. One block = 32x8 outputs; the 40x16 texel neighbourhood is staged in LDS once
 // instead of being fetched 49 times per output.
-__global__ __launch_bounds__(kBlurTX* kBlurTY) void blur_kernel(const float4* __restrict__ pre, float4* __restrict__ tmp, int W, int H,
+__global__ __launch_bounds__(kBlurTX* kBlurTY) void blur_kernel(const float4* __restrict__ pre, float4* __restrict__ tmp, int S, int W, int H,
                                                                   int preW, int preH, int rw, int rh) {
     __shared__ float4 tile[kTileH][kTileW];
     const int bx0 = blockIdx.x * kBlurTX, by0 = blockIdx.y * kBlurTY;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kBlurTX* kBlurTY) void blur_kernel(const float4* __
         int gx = bx0 - kApron + lx, gy = by0 - kApron + ly;
         // texelFetch outside the texture returns 0; `pre` is only valid on [0,preW) x [0,preH)
         bool ok = gx >= 0 && gy >= 0 && gx < W && gy < H && gx < preW && gy < preH;
-        tile[ly][lx] = ok ? pre[(size_t)gy * W + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tile[ly][lx] = ok ? pre[(size_t)gy * S + gx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
@@ -105,16 +106,16 @@ __global__ __launch_bounds__(kBlurTX* kBlurTY) void blur_kernel(const float4* __
         }
     }
     float d = (float)(n > 1 ? n : 1);
-    tmp[(size_t)y * W + x] = make_float4(col[0] / d, col[1] / d, col[2] / d, 0.0f);
+    tmp[(size_t)y * S + x] = make_float4(col[0] / d, col[1] / d, col[2] / d, 0.0f);
 }
 
 // Keeps what the GL_LINEAR up-blit of level i would read: tmp[0:w+1, 0:h+1], the corner plus the one texel of
 // bleed beyond it (CLAMP_TO_EDGE acts at the texture edge, not at the source rectangle, so that texel is whatever
 // earlier passes left in tmp). The next level overwrites the corner, hence the copy.
-__global__ void snap_kernel(const float4* __restrict__ tmp, float4* __restrict__ snap, int W, int sw, int sh) {
+__global__ void snap_kernel(const float4* __restrict__ tmp, float4* __restrict__ snap, int S, int sw, int sh) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= sw || y >= sh) return;
-    snap[(size_t)y * sw + x] = tmp[(size_t)y * W + x];
+    snap[(size_t)y * sw + x] = tmp[(size_t)y * S + x];
 }
 
 struct LevelView { const float4* snap; int w, h, sw, sh; };
@@ -137,10 +138,17 @@ __device__ __forceinline__ float4 up_sample(const LevelView& L, int x, int y, in
     return o;
 }
 
+// glGetTexImage(GL_RGB, GL_UNSIGNED_BYTE) of a float texture: clamp to [0,1], scale by 255, round to nearest.
+__device__ __forceinline__ uint8_t to_unorm8(float f) {
+    f = !(f > 0.0f) ? 0.0f : (f > 1.0f ? 1.0f : f);
+    return (uint8_t)(int)rintf(f * 255.0f);
+}
+
 // Fi:17-30, with the four up-blits of main.cpp:262-268 evaluated in place: the reference first writes each level,
 // enlarged to the whole window, into a texture of its own and reads the four back here; the values added are the same.
+// The result goes to a row-major float image and/or to its 8-bit read-back (either may be NULL).
 __global__ void final_kernel(AccumView accum, LevelView l0, LevelView l1, LevelView l2, LevelView l3,
-                             float4* __restrict__ tmp, int W, int H) {
+                             float4* __restrict__ outRgba, uint8_t* __restrict__ outRgb8, int W, int H) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= W || y >= H) return;
     const size_t i = (size_t)y * W + x;
@@ -151,20 +159,15 @@ __global__ void final_kernel(AccumView accum, LevelView l0, LevelView l1, LevelV
     r += a.x; r += b.x; r += c.x; r += d.x;
     gr += a.y; gr += b.y; gr += c.y; gr += d.y;
     bl += a.z; bl += b.z; bl += c.z; bl += d.z;
-    tmp[i] = make_float4(r, gr, bl, 0.0f);
+    if (outRgba) outRgba[i] = make_float4(r, gr, bl, 0.0f);
+    if (outRgb8) { outRgb8[i * 3 + 0] = to_unorm8(r); outRgb8[i * 3 + 1] = to_unorm8(gr); outRgb8[i * 3 + 2] = to_unorm8(bl); }
 }
 
-// glGetTexImage(GL_RGB, GL_UNSIGNED_BYTE) of a float texture: clamp to [0,1], scale by 255, round to nearest.
 __global__ void to_rgb8_kernel(const float4* __restrict__ img, uint8_t* __restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = img[i];
-    float v[3] = {p.x, p.y, p.z};
-    for (int k = 0; k < 3; ++k) {
-        float f = v[k];
-        f = !(f > 0.0f) ? 0.0f : (f > 1.0f ? 1.0f : f);
-        out[i * 3 + k] = (uint8_t)(int)rintf(f * 255.0f);
-    }
+    out[i * 3 + 0] = to_unorm8(p.x); out[i * 3 + 1] = to_unorm8(p.y); out[i * 3 + 2] = to_unorm8(p.z);
 }
 
 struct PostScratch {
@@ -197,6 +200,42 @@ void Regions(int W, int H, int rw[kLevels], int rh[kLevels]) {
         if (rh[i] > H) rh[i] = H;
         needW = rw[i] + kApron; needH = rh[i] + kApron;
     }
+}
+
+// The buffers one run of the chain works in. tmp and pre have `stride` texels per row and at least
+// ChainRows() rows of ChainCols() texels; snap[i] holds sw[i] x sh[i] texels.
+struct ChainBuffers {
+    float4* tmp; float4* pre; int stride;
+    float4* snap[kLevels]; int sw[kLevels], sh[kLevels];
+};
+
+void SnapSizes(int W, int H, int sw[kLevels], int sh[kLevels]) {
+    const int ds[kLevels] = {5, 10, 20, 40};
+    for (int i = 0; i < kLevels; ++i) { sw[i] = min(W / ds[i] + 1, W); sh[i] = min(H / ds[i] + 1, H); }
+}
+// The part of tmp / pre the level passes touch: everything lies in [0, ChainCols) x [0, ChainRows).
+int ChainCols(int W, int H) { int rw[kLevels], rh[kLevels]; Regions(W, H, rw, rh); return min(W, rw[0] + kApron); }
+int ChainRows(int W, int H) { int rw[kLevels], rh[kLevels]; Regions(W, H, rw, rh); return min(H, rh[0] + kApron); }
+
+// Queues the level passes and the final composite on `st`.
+void LaunchChain(hipStream_t st, const AccumView& view, int W, int H, const ChainBuffers& cb, float4* outRgba, uint8_t* outRgb8) {
+    const dim3 b2(32, 8);
+    auto grid2 = [&](int w, int h) { return dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)); };
+    const int ds[kLevels] = {5, 10, 20, 40};
+    const int S = cb.stride;
+    int rw[kLevels], rh[kLevels];
+    Regions(W, H, rw, rh);
+    LevelView lv[kLevels];
+    for (int i = 0; i < kLevels; ++i) {
+        const int w = W / ds[i], h = H / ds[i];
+        if (w > 0 && h > 0) hipLaunchKernelGGL(down_kernel, grid2(w, h), b2, 0, st, view, cb.tmp, S, W, H, w, h);
+        const int pw = min(W, rw[i] + kApron), ph = min(H, rh[i] + kApron);
+        hipLaunchKernelGGL(pre_kernel, grid2(pw, ph), b2, 0, st, cb.tmp, cb.pre, S, pw, ph);
+        hipLaunchKernelGGL(blur_kernel, grid2(rw[i], rh[i]), dim3(kBlurTX, kBlurTY), 0, st, cb.pre, cb.tmp, S, W, H, pw, ph, rw[i], rh[i]);
+        hipLaunchKernelGGL(snap_kernel, grid2(cb.sw[i], cb.sh[i]), b2, 0, st, cb.tmp, cb.snap[i], S, cb.sw[i], cb.sh[i]);
+        lv[i] = LevelView{cb.snap[i], w, h, cb.sw[i], cb.sh[i]};
+    }
+    hipLaunchKernelGGL(final_kernel, grid2(W, H), b2, 0, st, view, lv[0], lv[1], lv[2], lv[3], outRgba, outRgb8, W, H);
 }
 
 }  // namespace
@@ -234,13 +273,8 @@ int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint
         hipError_t e = hipMalloc((void**)&s->tmp, n * 16);
         if (e == hipSuccess) e = hipMemsetAsync(s->tmp, 0, n * 16, st);
         if (e == hipSuccess) e = hipMalloc((void**)&s->pre, n * 16);
-        {
-            const int dsz[kLevels] = {5, 10, 20, 40};
-            for (int i = 0; i < kLevels && e == hipSuccess; ++i) {
-                s->sw[i] = min((int)width / dsz[i] + 1, (int)width); s->sh[i] = min((int)height / dsz[i] + 1, (int)height);
-                e = hipMalloc((void**)&s->snap[i], (size_t)s->sw[i] * s->sh[i] * 16);
-            }
-        }
+        SnapSizes((int)width, (int)height, s->sw, s->sh);
+        for (int i = 0; i < kLevels && e == hipSuccess; ++i) e = hipMalloc((void**)&s->snap[i], (size_t)s->sw[i] * s->sh[i] * 16);
         if (e == hipSuccess) e = hipMalloc((void**)&s->rgb8, n * 3);
         if (e != hipSuccess) { Release(s); err = hipGetErrorString(e); return RT_ERR_DEVICE; }
         s->W = width; s->H = height;
@@ -249,28 +283,13 @@ int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint
     if (!bloomOn && tilesX != 0) { err = "the raw path needs the row-major image"; return RT_ERR_INVALID; }
     const float4* accum = static_cast<const float4*>(accumImage);
     const AccumView view{accum, (int)width, (int)tilesX};
-    const dim3 b2(32, 8);
-    auto grid2 = [&](int w, int h) { return dim3((unsigned)((w + 31) / 32), (unsigned)((h + 7) / 8)); };
-    if (bloomOn) {
-        const int ds[kLevels] = {5, 10, 20, 40};
-        int rw[kLevels], rh[kLevels];
-        Regions(W, H, rw, rh);
-        for (int i = 0; i < kLevels; ++i) {
-            const int w = W / ds[i], h = H / ds[i];
-            if (w > 0 && h > 0) hipLaunchKernelGGL(down_kernel, grid2(w, h), b2, 0, st, view, s->tmp, W, H, w, h);
-            const int pw = min(W, rw[i] + kApron), ph = min(H, rh[i] + kApron);
-            hipLaunchKernelGGL(pre_kernel, grid2(pw, ph), b2, 0, st, s->tmp, s->pre, W, pw, ph);
-            hipLaunchKernelGGL(blur_kernel, grid2(rw[i], rh[i]), dim3(kBlurTX, kBlurTY), 0, st, s->pre, s->tmp, W, H, pw, ph, rw[i], rh[i]);
-            hipLaunchKernelGGL(snap_kernel, grid2(s->sw[i], s->sh[i]), b2, 0, st, s->tmp, s->snap[i], W, s->sw[i], s->sh[i]);
-        }
-    }
     // bloom off = the raw blit of main.cpp:235-240: the accumulation is shown as it is and tmp is left alone
     const float4* shown = accum;
     if (bloomOn) {
-        const int dsz[kLevels] = {5, 10, 20, 40};
-        LevelView lv[kLevels];
-        for (int i = 0; i < kLevels; ++i) lv[i] = LevelView{s->snap[i], W / dsz[i], H / dsz[i], s->sw[i], s->sh[i]};
-        hipLaunchKernelGGL(final_kernel, grid2(W, H), b2, 0, st, view, lv[0], lv[1], lv[2], lv[3], s->tmp, W, H);
+        ChainBuffers cb;
+        cb.tmp = s->tmp; cb.pre = s->pre; cb.stride = W;
+        for (int i = 0; i < kLevels; ++i) { cb.snap[i] = s->snap[i]; cb.sw[i] = s->sw[i]; cb.sh[i] = s->sh[i]; }
+        LaunchChain(st, view, W, H, cb, s->tmp, nullptr);       // the composite replaces tmp, as in the reference
         shown = s->tmp;
     }
     if (hipGetLastError() != hipSuccess) { err = "kernel launch failed"; return RT_ERR_DEVICE; }
@@ -284,3 +303,89 @@ int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint
 }
 
 }  // namespace rtd
+
+// ---------------------------------------------------------------------------------------------------------------
+// rt_postprocess_static: the bloom chain for callers that must not allocate (code under HIP graph capture, tight
+// serving loops). Same kernels as rt_postprocess; what that entry point keeps in buffers it allocates per context
+// (the working images tmp and pre, cut down to the corner the level passes touch, and the four level snapshots)
+// lives here in one fixed array in device memory, one copy per GPU the library is loaded on.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t kStaticScratchBytes = 20u << 20;      // enough for a 3840 x 2160 image (17.9 MB)
+constexpr int kMaxStaticDevices = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+// The array's address on each device, looked up once per device with that device current. In host code the name
+// `scratch` is only a handle for this lookup; kernels and memsets get the pointer kept here.
+void* g_staticScratch[kMaxStaticDevices];
+bool g_staticScratchKnown[kMaxStaticDevices];
+
+hipError_t StaticScratchOfCurrentDevice(void** out, int* deviceOut) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxStaticDevices) return hipErrorInvalidDevice;
+    if (!g_staticScratchKnown[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_staticScratch[dev] = p;
+        g_staticScratchKnown[dev] = true;
+    }
+    *out = g_staticScratch[dev];
+    if (deviceOut) *deviceOut = dev;
+    return hipSuccess;
+}
+}  // namespace
+
+namespace rtd {
+void SetGlobalError(const char* fmt, ...);
+// Called by rt_create with the context's device current, so that the address is known before a caller that cannot
+// afford the lookup (graph capture) makes its first rt_postprocess_static call on that device.
+int PrepareStaticScratch() {
+    void* p = nullptr;
+    return StaticScratchOfCurrentDevice(&p, nullptr) == hipSuccess ? RT_OK : RT_ERR_DEVICE;
+}
+}  // namespace rtd
+
+extern "C" int rt_postprocess_static(const float* accumDevice, uint32_t width, uint32_t height, float* rgbaOutDevice, uint8_t* rgb8OutDevice,
+                                     void* hipStream) {
+    using namespace rtd;
+    if (!accumDevice || (!rgbaOutDevice && !rgb8OutDevice)) { SetGlobalError("rt_postprocess_static: NULL image"); return RT_ERR_INVALID; }
+    if (width == 0 || height == 0 || width > 32768 || height > 32768) { SetGlobalError("rt_postprocess_static: bad image size %ux%u", width, height); return RT_ERR_INVALID; }
+    const int W = (int)width, H = (int)height;
+    // carve the fixed array: tmp, pre (both cols x rows texels), then the four snapshots; every piece 256-byte aligned
+    const int cols = ChainCols(W, H), rows = ChainRows(W, H);
+    ChainBuffers cb;
+    SnapSizes(W, H, cb.sw, cb.sh);
+    auto align = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
+    const size_t regionBytes = align((size_t)cols * rows * sizeof(float4));
+    size_t need = 2 * regionBytes;
+    size_t snapAt[kLevels];
+    for (int i = 0; i < kLevels; ++i) { snapAt[i] = need; need += align((size_t)cb.sw[i] * cb.sh[i] * sizeof(float4)); }
+    if (need > kStaticScratchBytes) {
+        SetGlobalError("rt_postprocess_static: a %ux%u image needs %zu bytes of working memory, the fixed array holds %zu (up to 3840x2160); "
+                       "use rt_postprocess", width, height, need, (size_t)kStaticScratchBytes);
+        return RT_ERR_UNSUPPORTED;
+    }
+    void* base = nullptr;
+    hipError_t e = StaticScratchOfCurrentDevice(&base, nullptr);
+    if (e != hipSuccess) { SetGlobalError("rt_postprocess_static: hipGetSymbolAddress: %s", hipGetErrorString(e)); return RT_ERR_DEVICE; }
+    unsigned char* b = static_cast<unsigned char*>(base);
+    cb.tmp = reinterpret_cast<float4*>(b); cb.pre = reinterpret_cast<float4*>(b + regionBytes); cb.stride = cols;
+    for (int i = 0; i < kLevels; ++i) cb.snap[i] = reinterpret_cast<float4*>(b + snapAt[i]);
+    hipStream_t st = (hipStream_t)hipStream;
+    // The array keeps what the last call left in it. tmp must start as a freshly created texture does (zero: the level
+    // passes read texels of it that nothing has written yet); pre and the snapshots are written before they are read.
+    e = hipMemsetAsync(cb.tmp, 0, (size_t)cols * rows * sizeof(float4), st);
+    if (e != hipSuccess) { SetGlobalError("rt_postprocess_static: hipMemsetAsync: %s", hipGetErrorString(e)); return RT_ERR_DEVICE; }
+    const AccumView view{reinterpret_cast<const float4*>(accumDevice), W, 0};
+    LaunchChain(st, view, W, H, cb, reinterpret_cast<float4*>(rgbaOutDevice), rgb8OutDevice);
+    e = hipGetLastError();
+    if (e != hipSuccess) { SetGlobalError("rt_postprocess_static: kernel launch: %s", hipGetErrorString(e)); return RT_ERR_DEVICE; }
+    return RT_OK;
+}

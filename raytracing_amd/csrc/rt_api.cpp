@@ -31,11 +31,21 @@ int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 void FreePostprocess(void** scratch);
+int PrepareStaticScratch();
+void SetGlobalError(const char* fmt, ...);
 }  // namespace rtd
 
 using namespace rtd;
 
 static thread_local std::string g_globalError;
+
+namespace rtd {
+void SetGlobalError(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_globalError = buf;
+}
+}  // namespace rtd
 
 struct rt_context {
     int device = 0;
@@ -166,6 +176,7 @@ int rt_create(int device, uint32_t width, uint32_t height, rt_context** out) {
     if (e != hipSuccess || count <= 0) return Fail(nullptr, RT_ERR_DEVICE, "rt_create: no HIP device available (%s)", hipGetErrorString(e));
     if (device < 0 || device >= count) return Fail(nullptr, RT_ERR_INVALID, "rt_create: device %d out of range (have %d)", device, count);
     HIP_TRY(nullptr, hipSetDevice(device));
+    if (PrepareStaticScratch() != RT_OK) return Fail(nullptr, RT_ERR_DEVICE, "rt_create: cannot locate the library's device-side working array");
     rt_context* c = new rt_context();
     c->device = device; c->width = width; c->height = height;
     SceneParams& sp = c->sp;
