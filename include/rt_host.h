@@ -102,6 +102,30 @@ void rth_app_push_pose(rth_app *app, const float *position3, const float *facing
 int rth_app_save_poses(const rth_app *app, const char *path);
 int rth_app_load_poses(rth_app *app, const char *path);
 
+/* ---- offline video: the playback half of Include/Recorder.h:36-55,93-103 as a batch job ----
+ * Pose k (poses6 = px py pz fx fy fz per pose) gets `samplesPerPixel` progressive frames in one launch, seeded with
+ * frames k*spp .. (k+1)*spp-1 of the reference's rand() stream, then one run of the bloom chain, and is written as
+ * <outputDir>/raytrace-out-<k>.png (Recorder::WriteTexture's name and row order). This process renders the poses with
+ * k % world == rank on `ctx` (scene, textures, bounce limit already set); encoding and writing run on writer threads
+ * while the next pose is traced; with RTH_VIDEO_RESUME poses whose file exists are skipped. */
+typedef struct rth_video_stats {
+    uint32_t rendered, skipped, written, write_failures;
+    double wall_seconds;      /* the whole call */
+    double trace_seconds;     /* tracer kernel time, HIP events */
+    double encode_seconds;    /* writer threads busy, summed (overlaps with tracing) */
+    double stall_seconds;     /* render loop blocked because the writers were behind */
+    uint64_t rays;
+} rth_video_stats;
+enum { RTH_VIDEO_BLOOM = 1, RTH_VIDEO_FLIP = 2, RTH_VIDEO_RESUME = 4, RTH_VIDEO_WRITE = 8 };
+int rth_video_render(rt_context *ctx, uint32_t width, uint32_t height, const float *poses6, uint32_t nPoses,
+                     uint32_t samplesPerPixel, uint32_t rank, uint32_t world, const char *outputDir, uint32_t flags,
+                     int compression, uint32_t writerThreads, rth_video_stats *out);
+/* The u_RandSeed triples of poses firstPose .. firstPose+nPoses-1: out3 = float[nPoses * samplesPerPixel * 3]. */
+void rth_video_seeds(uint32_t firstPose, uint32_t nPoses, uint32_t samplesPerPixel, float *out3);
+/* Reads a pose file (one pose per line: px py pz fx fy fz, what rth_app_save_poses writes). *nPoses receives the
+ * number of poses in the file; at most `capacity` of them are stored in poses6 (which may be NULL to count). */
+int rth_read_poses(const char *path, float *poses6, uint32_t capacity, uint32_t *nPoses);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,12 @@ class rth_bvh_stats(ctypes.Structure):
                 ("degenerate_splits", ctypes.c_uint64), ("leaf_depth_sum", ctypes.c_uint64), ("build_ms", ctypes.c_double)]
 
 
+class rth_video_stats(ctypes.Structure):
+    _fields_ = [("rendered", ctypes.c_uint32), ("skipped", ctypes.c_uint32), ("written", ctypes.c_uint32), ("write_failures", ctypes.c_uint32),
+                ("wall_seconds", ctypes.c_double), ("trace_seconds", ctypes.c_double), ("encode_seconds", ctypes.c_double),
+                ("stall_seconds", ctypes.c_double), ("rays", ctypes.c_uint64)]
+
+
 class rth_app_state(ctypes.Structure):
     _fields_ = [("camera", ctypes.c_float * 9), ("last_seed", ctypes.c_float * 3), ("next_frame_index", ctypes.c_uint32),
                 ("bounce_limit", ctypes.c_uint32), ("recorder_state", ctypes.c_int32), ("poses_left", ctypes.c_uint32),
@@ -106,6 +112,9 @@ SIGNATURES = {
     "rth_app_push_pose": (None, [P, P, P]),
     "rth_app_save_poses": (I, [P, ctypes.c_char_p]),
     "rth_app_load_poses": (I, [P, ctypes.c_char_p]),
+    "rth_video_render": (I, [P, U32, U32, P, U32, U32, U32, U32, ctypes.c_char_p, U32, I, U32, ctypes.POINTER(rth_video_stats)]),
+    "rth_video_seeds": (None, [U32, U32, U32, P]),
+    "rth_read_poses": (I, [ctypes.c_char_p, P, U32, ctypes.POINTER(U32)]),
 }
 
 _lib = None

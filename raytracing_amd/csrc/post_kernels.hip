@@ -248,6 +248,13 @@ void FreePostprocess(void** scratch) {
     *scratch = nullptr;
 }
 
+// Back to the state of a freshly started process: the tmp image is cleared (the buffers stay).
+int ResetPostprocess(hipStream_t st, void** scratch) {
+    PostScratch* s = scratch ? static_cast<PostScratch*>(*scratch) : nullptr;
+    if (!s || !s->tmp) return RT_OK;
+    return hipMemsetAsync(s->tmp, 0, (size_t)s->W * s->H * 16, st) == hipSuccess ? RT_OK : RT_ERR_DEVICE;
+}
+
 int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err) {
     PostScratch* s = scratch ? static_cast<PostScratch*>(*scratch) : nullptr;
     if (!s || s->W != width || s->H != height) { err = "nothing on display yet (run rt_postprocess with bloom_on = 1 first)"; return RT_ERR_STATE; }

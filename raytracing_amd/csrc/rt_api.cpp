@@ -31,6 +31,7 @@ int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 void FreePostprocess(void** scratch);
+int ResetPostprocess(hipStream_t st, void** scratch);
 int PrepareStaticScratch();
 void SetGlobalError(const char* fmt, ...);
 }  // namespace rtd
@@ -648,8 +649,8 @@ int rt_display_read(rt_context* c, float* rgba_out, uint8_t* rgb8_out) {
 int rt_display_reset(rt_context* c) {
     if (!c) return RT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    FreePostprocess(&c->postScratch);      // the next rt_postprocess starts from a zeroed tmp image
+    // the next rt_postprocess starts from a zeroed tmp image (queued on the stream; the buffers are kept)
+    if (ResetPostprocess(c->stream, &c->postScratch) != RT_OK) return Fail(c, RT_ERR_DEVICE, "rt_display_reset: clearing the display image failed");
     return RT_OK;
 }
 

@@ -1,6 +1,7 @@
 #include "app.h"
 
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include <cstdio>
 #include <fstream>
@@ -13,59 +14,40 @@ namespace rta {
 
 // ------------------------------------------------------------------------------------------ PNG
 namespace {
-uint32_t Crc32(const uint8_t* p, size_t n, uint32_t crc) {
-    static uint32_t table[256];
-    static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
-        init = true;
-    }
-    crc = ~crc;
-    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
-    return ~crc;
-}
 void Put32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
-void Chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
-    Put32(out, (uint32_t)data.size());
-    std::vector<uint8_t> body(type, type + 4);
-    body.insert(body.end(), data.begin(), data.end());
-    out.insert(out.end(), body.begin(), body.end());
-    Put32(out, Crc32(body.data(), body.size(), 0));
+void Chunk(std::vector<uint8_t>& out, const char* type, const uint8_t* data, size_t n) {
+    Put32(out, (uint32_t)n);
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data, data + n);
+    Put32(out, (uint32_t)crc32(0L, out.data() + at, (uInt)(n + 4)));
 }
 }  // namespace
 
-bool WritePngRgb8(const std::string& path, uint32_t width, uint32_t height, const uint8_t* rgb, bool flip) {
+bool WritePngRgb8(const std::string& path, uint32_t width, uint32_t height, const uint8_t* rgb, bool flip, int compression) {
+    if (!width || !height || !rgb) return false;
     std::vector<uint8_t> raw;
-    raw.reserve((size_t)height * (width * 3 + 1));
+    raw.reserve((size_t)height * ((size_t)width * 3 + 1));
     for (uint32_t y = 0; y < height; ++y) {
         const uint8_t* row = rgb + (size_t)(flip ? height - 1 - y : y) * width * 3;
         raw.push_back(0);                                   // filter: none
         raw.insert(raw.end(), row, row + (size_t)width * 3);
     }
-    std::vector<uint8_t> z = {0x78, 0x01};                  // zlib header, stored blocks
-    uint32_t a = 1, b = 0;
-    for (uint8_t c : raw) { a = (a + c) % 65521; b = (b + a) % 65521; }
-    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
-        size_t n = std::min<size_t>(65535, raw.size() - pos);
-        bool last = pos + n >= raw.size();
-        z.push_back(last ? 1 : 0);
-        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
-        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
-        pos += n;
-        if (last) break;
-    }
-    Put32(z, (b << 16) | a);
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), compression < 0 ? 0 : (compression > 9 ? 9 : compression)) != Z_OK) return false;
     std::vector<uint8_t> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    png.reserve(zlen + 64);
     std::vector<uint8_t> ihdr;
     Put32(ihdr, width); Put32(ihdr, height);
     ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});               // 8 bits, colour type RGB
-    Chunk(png, "IHDR", ihdr);
-    Chunk(png, "IDAT", z);
-    Chunk(png, "IEND", {});
+    Chunk(png, "IHDR", ihdr.data(), ihdr.size());
+    Chunk(png, "IDAT", z.data(), zlen);
+    Chunk(png, "IEND", nullptr, 0);
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return false;
     bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
-    std::fclose(f);
+    ok = (std::fclose(f) == 0) && ok;
     return ok;
 }
 

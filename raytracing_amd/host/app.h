@@ -100,7 +100,8 @@ private:
     bool displayValid_ = false;
 };
 
-// Minimal PNG writer (8-bit RGB, stored deflate blocks). Rows are written in the order given.
-bool WritePngRgb8(const std::string& path, uint32_t width, uint32_t height, const uint8_t* rgb, bool flipVertically);
+// PNG writer (8-bit RGB; `compression` is the zlib level of the image data, 0 = stored). Rows are written in the order
+// given, or bottom row first with flipVertically.
+bool WritePngRgb8(const std::string& path, uint32_t width, uint32_t height, const uint8_t* rgb, bool flipVertically, int compression = 0);
 
 }  // namespace rta

@@ -5,6 +5,11 @@
 //   raytracer_headless [--ini RayTracer.ini] [--noise ./Textures/Noise/rgbNoise.png]
 //                      [--width 1280 --height 720] [--frames 64] [--device 0] [--threads 8]
 //                      [--keys "K4 W+ 10 W- 50"] [--poses file --spp 256] [--out shots] [--no-bloom] [--flip]
+//                      [--offline [--rank r --world n]]
+// --poses alone replays the Recorder's playback frame by frame (one launch and one bloom pass per displayed frame, as
+// the reference does). --poses with --offline is the batch form: all samples of a pose in one launch, images written by
+// writer threads, existing images skipped; start one process per GPU with --device r --rank r --world n to share the
+// poses of a job among n GPUs.
 // --keys: tokens separated by blanks: NAME = tap, NAME+ = press, NAME- = release, a number = that many frames.
 #include <cctype>
 #include <cstdio>
@@ -17,6 +22,7 @@
 
 #include "app.h"
 #include "image_io.h"
+#include "video.h"
 #include "rt_mi355x.h"
 
 using namespace rta;
@@ -30,7 +36,8 @@ int main(int argc, char** argv) {
     std::string ini = "RayTracer.ini", noisePath = "./Textures/Noise/rgbNoise.png", keys, poses, outDir = "shots";
     uint32_t width = 1280, height = 720, frames = 64, spp = 256;   // window size of src/main.cpp:28-29
     int device = 0, threads = 8;
-    bool bloom = true, flip = false;
+    uint32_t rank = 0, world = 1;
+    bool bloom = true, flip = false, offline = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -39,6 +46,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = std::atoi(next()); else if (a == "--threads") threads = std::atoi(next());
         else if (a == "--keys") keys = next(); else if (a == "--poses") poses = next(); else if (a == "--spp") spp = std::atoi(next());
         else if (a == "--out") outDir = next(); else if (a == "--no-bloom") bloom = false; else if (a == "--flip") flip = true;
+        else if (a == "--offline") offline = true; else if (a == "--rank") rank = std::atoi(next()); else if (a == "--world") world = std::atoi(next());
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     std::string skyDir;
@@ -82,7 +90,16 @@ int main(int argc, char** argv) {
         {"LEFT", kKeyLeft}, {"RIGHT", kKeyRight}, {"GRAVE", kKeyGrave}, {"K1", kKey1}, {"K2", kKey2}, {"K3", kKey3}, {"K4", kKey4},
         {"K5", kKey5}, {"K6", kKey6}};
     auto run = [&](uint32_t n) { for (uint32_t k = 0; k < n; ++k) if (app.Tick() != RT_OK) return false; return true; };
-    if (!poses.empty()) {
+    if (!poses.empty() && offline) {
+        VideoJob job;
+        if (!ReadPoseFile(poses, job.poses)) return Die("cannot read the pose file");
+        job.samplesPerPixel = spp; job.rank = rank; job.world = world; job.outputDir = outDir; job.bloom = bloom; job.flipVertically = flip;
+        VideoStats vs;
+        if (RenderVideo(ctx, width, height, job, &vs) != RT_OK) return Die("rendering", ctx);
+        std::printf("rank %u of %u: rendered %u poses, skipped %u, wrote %u images to %s in %.3f s (tracing %.3f s, %.1f Mrays/s)\n", rank, world,
+                    vs.rendered, vs.skipped, vs.written, outDir.c_str(), vs.wallSeconds, vs.traceSeconds,
+                    vs.wallSeconds > 0 ? vs.rays / vs.wallSeconds / 1e6 : 0.0);
+    } else if (!poses.empty()) {
         if (!rec.LoadPoses(poses)) return Die("cannot read the pose file");
         const uint32_t total = (uint32_t)rec.PosesLeft();
         app.OnKey(kKeyP, kPress); app.OnKey(kKeyP, kRelease);

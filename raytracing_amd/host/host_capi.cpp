@@ -120,6 +120,7 @@ int rth_scene_send(const rth_scene* s, rt_context* ctx) {
 #include "app.h"
 #include "controls.h"
 #include "image_io.h"
+#include "video.h"
 
 struct rth_camera { rta::Camera cam; };
 struct rth_app { rta::HeadlessApp app; rth_app(rt_context* c, uint32_t w, uint32_t h) : app(c, w, h) {} };
@@ -223,6 +224,55 @@ int rth_app_save_poses(const rth_app* a, const char* path) {
 int rth_app_load_poses(rth_app* a, const char* path) {
     if (!a || !path) return RT_ERR_INVALID;
     return Guarded([&] { return a->app.GetRecorder().LoadPoses(path) ? (int)RT_OK : (int)RT_ERR_INVALID; });
+}
+
+int rth_video_render(rt_context* ctx, uint32_t width, uint32_t height, const float* poses6, uint32_t nPoses, uint32_t spp, uint32_t rank,
+                     uint32_t world, const char* outputDir, uint32_t flags, int compression, uint32_t writerThreads, rth_video_stats* out) {
+    if (!ctx || (nPoses && !poses6)) return RT_ERR_INVALID;
+    return Guarded([&] {
+        rta::VideoJob job;
+        for (uint32_t k = 0; k < nPoses; ++k) {
+            const float* p = poses6 + 6 * (size_t)k;
+            job.poses.push_back(rta::Pose{{p[0], p[1], p[2]}, {p[3], p[4], p[5]}});
+        }
+        job.samplesPerPixel = spp; job.rank = rank; job.world = world;
+        if (outputDir) job.outputDir = outputDir;
+        job.bloom = (flags & RTH_VIDEO_BLOOM) != 0; job.flipVertically = (flags & RTH_VIDEO_FLIP) != 0;
+        job.resume = (flags & RTH_VIDEO_RESUME) != 0; job.writeImages = (flags & RTH_VIDEO_WRITE) != 0;
+        job.compression = compression; job.writerThreads = writerThreads ? writerThreads : 2;
+        rta::VideoStats st;
+        int rc = rta::RenderVideo(ctx, width, height, job, &st);
+        if (out) {
+            out->rendered = st.rendered; out->skipped = st.skipped; out->written = st.written; out->write_failures = st.writeFailures;
+            out->wall_seconds = st.wallSeconds; out->trace_seconds = st.traceSeconds; out->encode_seconds = st.encodeSeconds;
+            out->stall_seconds = st.stallSeconds; out->rays = st.rays;
+        }
+        return rc;
+    });
+}
+
+void rth_video_seeds(uint32_t firstPose, uint32_t nPoses, uint32_t spp, float* out3) {
+    if (!out3) return;
+    (void)Guarded([&] {
+        std::vector<float> s = rta::VideoSeeds(firstPose, nPoses, spp);
+        std::memcpy(out3, s.data(), s.size() * sizeof(float));
+        return (int)RT_OK;
+    });
+}
+
+int rth_read_poses(const char* path, float* poses6, uint32_t capacity, uint32_t* nPoses) {
+    if (!path || !nPoses) return RT_ERR_INVALID;
+    return Guarded([&] {
+        std::vector<rta::Pose> poses;
+        if (!rta::ReadPoseFile(path, poses)) return (int)RT_ERR_INVALID;
+        *nPoses = (uint32_t)poses.size();
+        for (uint32_t k = 0; poses6 && k < capacity && k < poses.size(); ++k) {
+            const rta::Pose& p = poses[k];
+            float* o = poses6 + 6 * (size_t)k;
+            o[0] = p.position.x; o[1] = p.position.y; o[2] = p.position.z; o[3] = p.facing.x; o[4] = p.facing.y; o[5] = p.facing.z;
+        }
+        return (int)RT_OK;
+    });
 }
 
 }  // extern "C"

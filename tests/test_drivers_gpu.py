@@ -1,0 +1,70 @@
+"""The multi-rank drivers as the round-end harness starts them: fresh child processes under torch.distributed.run.
+
+bench.py: the sharded step loop (render -> export -> double-buffered gather -> assemble) with the real nccl (= RCCL)
+backend on one rank (RT_BENCH_FORCE_DIST=1 sends a single rank through the whole exchange path) and, with two ranks
+sharing the one device, over gloo; --verify compares the assembled image with an unsharded render bit for bit.
+raytracing_amd.video: two ranks share a job's poses; the images equal a one-rank job's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_ranks(nproc, args, env_extra, port, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def last_json_line(text):
+    for line in reversed(text.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in:\n" + text)
+
+
+def test_bench_exchange_path_with_rccl_on_one_rank():
+    r = run_ranks(1, ["bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--verify", "--no-cpu-baseline"],
+                  {"RT_BENCH_FORCE_DIST": "1"}, 29541)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "verify: image assembled from 1 shards equals the unsharded render" in r.stderr
+    out = last_json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["config"]["parallelism"] == "tiles1" and out["value"] > 0
+
+
+def test_bench_two_ranks_over_gloo_assemble_the_unsharded_image():
+    r = run_ranks(2, ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--verify", "--no-cpu-baseline", "--workload", "teapot_like_1920x1080_b8"],
+                  {"RT_BENCH_BACKEND": "gloo"}, 29542)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "verify: image assembled from 2 shards equals the unsharded render" in r.stderr
+    out = last_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "tiles2" and out["scaling"] == "strong"
+
+
+def test_video_driver_two_ranks_write_the_images_of_a_one_rank_job(tmp_path):
+    common = ["-m", "raytracing_amd.video", "--poses", "5", "--spp", "3", "--width", "320", "--height", "200", "--bounces", "4",
+              "--scene", "sponza_like", "--tris", "20000"]
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    r2 = run_ranks(2, common + ["--out", two], {"RT_BENCH_BACKEND": "gloo"}, 29543)
+    assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
+    s2 = last_json_line(r2.stdout)
+    assert (s2["n_gpus"], s2["rendered"], s2["written"], s2["skipped"]) == (2, 5, 5, 0)
+    r1 = subprocess.run([sys.executable] + common + ["--out", one], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
+    s1 = last_json_line(r1.stdout)
+    assert (s1["n_gpus"], s1["rendered"], s1["written"]) == (1, 5, 5) and s1["mrays_per_s"] > 0
+    for k in range(5):
+        f = "raytrace-out-%d.png" % k
+        assert open(os.path.join(one, f), "rb").read() == open(os.path.join(two, f), "rb").read(), f
+    # running the two-rank job again resumes: nothing left to render
+    r3 = run_ranks(2, common + ["--out", two], {"RT_BENCH_BACKEND": "gloo"}, 29544)
+    assert r3.returncode == 0, r3.stdout[-3000:] + r3.stderr[-3000:]
+    s3 = last_json_line(r3.stdout)
+    assert (s3["rendered"], s3["skipped"]) == (0, 5)
