@@ -134,3 +134,37 @@ def test_sharded_equals_unsharded(workload, whole, world):
     assert differing_pixels(root.read_accum(), want) == 0
     assert total_rays == counters["rays"]
     root.close()
+
+
+@pytest.mark.parametrize("name", ["teapot_like_1920x1080_b8", "dragon_like_1920x1080_b16"])
+def test_other_full_size_workloads_equal_oracle(name):
+    """BASELINE configurations 2 and 3 at their own size: one 1920x1080 frame and the primary-hit ids, bit for bit.
+    The dragon-like tree (about 870 000 triangles, over 30 levels) makes rays spill stack entries to memory on real
+    geometry; its glass paths run to hundreds of segments."""
+    import bench
+    threads = min(16, os.cpu_count() or 1)
+    sc, W, H, bl = bench.load_workload(name, threads=threads)
+    assert (W, H) == (1920, 1080)
+    if name.startswith("dragon"):
+        assert sc.n_triangles > 800_000 and sc.stats["max_depth"] > 12 + 8    # deeper than the on-chip stack entries
+    noise, sky, seeds = scenes.noise_texture(), scenes.sky_cubemap(), scenes.frame_seeds(1)
+    g, o = ra.Renderer(W, H), Oracle(W, H, threads=threads)
+    bench.setup(g, sc, noise, sky, bl)
+    o.set_scene(sc.tri12, sc.matidx, sc.node8)
+    o.set_materials(sc.materials[:16])
+    fov = np.float32(120 * 0.01745329251994329576923690768489)
+    o.set_camera((0, 0, 0), (1, 0, 0), float(fov), float(np.float32(2.0 * np.tan(float(fov) / 2.0))))
+    o.set_noise(noise)
+    o.set_skybox(sky)
+    o.set_bounce_limit(bl)
+    g.render(0, seeds)
+    o.render(0, seeds)
+    a, b = g.read_accum(), o.read_accum()
+    assert np.isfinite(b[..., :3]).all()
+    assert differing_pixels(a, b) == 0
+    ids_g, ids_o = g.primary_ids(seeds[0]), o.primary_ids(seeds[0])
+    assert (ids_g[..., 0] == ids_o[..., 0]).all(), "triangle ids differ"
+    assert (ids_g[..., 1] == ids_o[..., 1]).all(), "hit distances differ"
+    assert (ids_g[..., 2] == ids_o[..., 2]).all(), "iterationsCount differs"
+    assert (ids_g[..., 0] >= 0).mean() > 0.05
+    g.close()
