@@ -66,7 +66,8 @@ def load_workload(name, threads):
         os.replace(f.name, paths_file)       # atomically: another process may be looking for it right now
     with open(paths_file) as f:
         paths = json.load(f)
-    return ra.load_scene(paths, build_threads=threads), W, H, bl
+    # parsed triangles and the built tree are kept next to the files, keyed by the files' bytes: later runs skip both steps
+    return ra.load_scene(paths, build_threads=threads, cache_dir=os.path.join(cache, "scene_cache")), W, H, bl
 
 
 def setup(r, sc, noise, sky, bl):

@@ -33,6 +33,14 @@ typedef struct rth_bvh_stats {      /* what BvhTree::BuildTree prints (src/BvhTr
  * and flattens. Replaces Scene::LoadObjects up to, not including, the GPU uploads. */
 int rth_scene_load(const char *const *paths, uint32_t nPaths, int buildThreads, rth_scene **out);
 
+/* The same through a binary cache (no counterpart in the reference, which parses and builds on every start:
+ * src/Scene.cpp:87-127): the flat arrays are stored in cacheDir under the SHA-256 of a format version and of the
+ * input files' bytes in order, and loaded from there when that key is found again; a blob that is damaged, of another
+ * version or made from other bytes is ignored and rewritten. cacheDir NULL or "" = rth_scene_load.
+ * *cacheHit (may be NULL) receives 1 when the scene came from the cache, else 0. */
+int rth_scene_load_cached(const char *const *paths, uint32_t nPaths, int buildThreads, const char *cacheDir,
+                          rth_scene **out, int *cacheHit);
+
 /* Same from memory: tri9 = 9 floats per triangle (three corners), matSlot = material slot per
  * triangle, materials = the material table. maxLeaf <= 0 selects the reference's default of 3. */
 int rth_scene_build(const float *tri9, const int32_t *matSlot, uint32_t nTri, const rt_material *materials,
@@ -89,6 +97,8 @@ typedef struct rth_app_state {
 int rth_app_create(rt_context *ctx, uint32_t width, uint32_t height, rth_app **out);
 void rth_app_destroy(rth_app *app);
 int rth_app_load_objects(rth_app *app, const char *const *paths, uint32_t nPaths, int buildThreads);
+/* Directory for rth_scene_load_cached's blobs, used by the app's later load_objects calls (NULL or "" = no cache). */
+void rth_app_set_scene_cache(rth_app *app, const char *cacheDir);
 void rth_app_key(rth_app *app, int glfwKey, int action);          /* key_callback, src/main.cpp:289-296 */
 int rth_app_tick(rth_app *app);                                   /* one loop iteration */
 int rth_app_read_display(rth_app *app, float *rgba, uint8_t *rgb8);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "rt_set_stream": (I, [P, P]),
     "rt_kernel_time": (I, [P, ctypes.POINTER(ctypes.c_double), U64P, I]),
     "rth_scene_load": (I, [ctypes.POINTER(ctypes.c_char_p), U32, I, ctypes.POINTER(P)]),
+    "rth_scene_load_cached": (I, [ctypes.POINTER(ctypes.c_char_p), U32, I, ctypes.c_char_p, ctypes.POINTER(P), ctypes.POINTER(I)]),
     "rth_scene_build": (I, [P, P, U32, P, U32, I, I, ctypes.POINTER(P)]),
     "rth_scene_free": (None, [P]),
     "rth_scene_triangle_count": (U32, [P]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "rth_app_create": (I, [P, U32, U32, ctypes.POINTER(P)]),
     "rth_app_destroy": (None, [P]),
     "rth_app_load_objects": (I, [P, ctypes.POINTER(ctypes.c_char_p), U32, I]),
+    "rth_app_set_scene_cache": (None, [P, ctypes.c_char_p]),
     "rth_app_key": (None, [P, I, I]),
     "rth_app_tick": (I, [P]),
     "rth_app_read_display": (I, [P, P, P]),

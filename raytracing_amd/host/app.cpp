@@ -8,6 +8,7 @@
 #include <sstream>
 
 #include "config_parser.h"
+#include "scene_cache.h"
 #include "rt_host.h"
 
 namespace rta {
@@ -119,7 +120,7 @@ std::vector<std::string> HeadlessApp::ObjectPathsFromIni(const std::string& iniP
 }
 
 int HeadlessApp::LoadObjects(const std::vector<std::string>& paths, int buildThreads) {
-    scene_ = LoadScene(paths, buildThreads);
+    scene_ = LoadSceneCached(paths, buildThreads, sceneCacheDir);
     int rc = rt_scene_upload(ctx_, scene_.tri12.data(), scene_.matIdx.data(), scene_.TriangleCount(), scene_.node8.data(), scene_.NodeCount());
     if (rc != RT_OK) return rc;
     std::vector<rt_material> mats;

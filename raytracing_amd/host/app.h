@@ -84,6 +84,7 @@ public:
     uint32_t Height() const { return height_; }
     const float* LastSeed() const { return lastSeed_; }
 
+    std::string sceneCacheDir;              // LoadObjects keeps parsed + built scenes here, keyed by the files' bytes (empty = off)
     bool bloom = true;                      // the reference's B key never takes effect (its key table is never written): bloom is always on
     bool postprocessEveryFrame = true;      // as the reference does; the tmp image then carries over frame to frame
 

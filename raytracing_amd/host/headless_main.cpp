@@ -5,7 +5,8 @@
 //   raytracer_headless [--ini RayTracer.ini] [--noise ./Textures/Noise/rgbNoise.png]
 //                      [--width 1280 --height 720] [--frames 64] [--device 0] [--threads 8]
 //                      [--keys "K4 W+ 10 W- 50"] [--poses file --spp 256] [--out shots] [--no-bloom] [--flip]
-//                      [--offline [--rank r --world n]]
+//                      [--offline [--rank r --world n]] [--cache dir]
+// --cache: keep the parsed objects and the built tree in that directory, keyed by the object files' bytes.
 // --poses alone replays the Recorder's playback frame by frame (one launch and one bloom pass per displayed frame, as
 // the reference does). --poses with --offline is the batch form: all samples of a pose in one launch, images written by
 // writer threads, existing images skipped; start one process per GPU with --device r --rank r --world n to share the
@@ -33,7 +34,7 @@ static int Die(const char* what, rt_context* ctx = nullptr) {
 }
 
 int main(int argc, char** argv) {
-    std::string ini = "RayTracer.ini", noisePath = "./Textures/Noise/rgbNoise.png", keys, poses, outDir = "shots";
+    std::string ini = "RayTracer.ini", noisePath = "./Textures/Noise/rgbNoise.png", keys, poses, outDir = "shots", cacheDir;
     uint32_t width = 1280, height = 720, frames = 64, spp = 256;   // window size of src/main.cpp:28-29
     int device = 0, threads = 8;
     uint32_t rank = 0, world = 1;
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = std::atoi(next()); else if (a == "--threads") threads = std::atoi(next());
         else if (a == "--keys") keys = next(); else if (a == "--poses") poses = next(); else if (a == "--spp") spp = std::atoi(next());
         else if (a == "--out") outDir = next(); else if (a == "--no-bloom") bloom = false; else if (a == "--flip") flip = true;
+        else if (a == "--cache") cacheDir = next();
         else if (a == "--offline") offline = true; else if (a == "--rank") rank = std::atoi(next()); else if (a == "--world") world = std::atoi(next());
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -75,6 +77,7 @@ int main(int argc, char** argv) {
 
     HeadlessApp app(ctx, width, height);
     app.bloom = bloom;
+    app.sceneCacheDir = cacheDir;
     if (app.LoadObjects(objects, threads) != RT_OK) return Die("loading objects", ctx);
     for (const std::string& w : app.Scene().warnings) std::printf("%s\n", w.c_str());
     const BvhStats& st = app.Scene().stats;

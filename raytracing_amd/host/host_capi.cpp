@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "scene_cache.h"
 #include "scene_data.h"
 
 // Nothing may throw across the C boundary: allocation failures and whatever else the C++ below raises
@@ -60,6 +61,20 @@ int rth_scene_load(const char* const* paths, uint32_t nPaths, int buildThreads, 
         std::vector<std::string> p;
         for (uint32_t i = 0; i < nPaths; ++i) p.emplace_back(paths[i] ? paths[i] : "");
         *out = Wrap(rta::LoadScene(p, buildThreads));
+        return (int)RT_OK;
+    });
+}
+
+int rth_scene_load_cached(const char* const* paths, uint32_t nPaths, int buildThreads, const char* cacheDir, rth_scene** out, int* cacheHit) {
+    if (!out || (nPaths && !paths)) return RT_ERR_INVALID;
+    *out = nullptr;
+    if (cacheHit) *cacheHit = 0;
+    return Guarded([&] {
+        std::vector<std::string> p;
+        for (uint32_t i = 0; i < nPaths; ++i) p.emplace_back(paths[i] ? paths[i] : "");
+        rta::CacheResult r = rta::CacheResult::kDisabled;
+        *out = Wrap(rta::LoadSceneCached(p, buildThreads, cacheDir ? cacheDir : "", &r));
+        if (cacheHit) *cacheHit = r == rta::CacheResult::kHit ? 1 : 0;
         return (int)RT_OK;
     });
 }
@@ -194,6 +209,7 @@ int rth_app_load_objects(rth_app* a, const char* const* paths, uint32_t n, int t
         return a->app.LoadObjects(p, threads);
     });
 }
+void rth_app_set_scene_cache(rth_app* a, const char* dir) { if (a) (void)Guarded([&] { a->app.sceneCacheDir = dir ? dir : ""; return (int)RT_OK; }); }
 void rth_app_key(rth_app* a, int key, int action) { a->app.OnKey(key, action); }
 int rth_app_tick(rth_app* a) { return a ? Guarded([&] { return a->app.Tick(); }) : (int)RT_ERR_INVALID; }
 int rth_app_read_display(rth_app* a, float* rgba, uint8_t* rgb8) { return a ? Guarded([&] { return a->app.ReadDisplay(rgba, rgb8); }) : (int)RT_ERR_INVALID; }

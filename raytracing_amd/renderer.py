@@ -68,15 +68,19 @@ class SceneData:
         return int(self.node8.size // 8)
 
 
-def load_scene(paths, build_threads=1):
-    """Scene::LoadObjects without the GPU part: parse files, merge, build the BVH, flatten."""
+def load_scene(paths, build_threads=1, cache_dir=None):
+    """Scene::LoadObjects without the GPU part: parse files, merge, build the BVH, flatten. With cache_dir the result
+    is kept there, keyed by the files' bytes, and read back on later calls (SceneData.cache_hit tells)."""
     L = _lib.lib()
     arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
     h = ctypes.c_void_p()
-    rc = L.rth_scene_load(arr, len(paths), build_threads, ctypes.byref(h))
+    hit = ctypes.c_int(0)
+    rc = L.rth_scene_load_cached(arr, len(paths), build_threads, cache_dir.encode() if cache_dir else None, ctypes.byref(h), ctypes.byref(hit))
     if rc != 0:
         raise RtError("rth_scene_load failed: %d" % rc)
-    return SceneData(h)
+    sc = SceneData(h)
+    sc.cache_hit = bool(hit.value)
+    return sc
 
 
 def build_scene(tri9, mat_slot, materials_rows=None, build_threads=1, max_leaf=0):

@@ -112,8 +112,8 @@ def main(argv=None):
         open(os.path.join(d, "done"), "w").close()
     if dist:
         dist.barrier()
-    paths = sorted(os.path.join(d, f) for f in os.listdir(d) if f not in ("done",) and not f.endswith(".rtcache"))
-    sc = ra.load_scene(paths, build_threads=min(16, os.cpu_count() or 1))
+    paths = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".txt", ".off")))
+    sc = ra.load_scene(paths, build_threads=min(16, os.cpu_count() or 1), cache_dir=os.path.join(d, "scene_cache"))
     poses = read_poses(args.pose_file) if args.pose_file else camera_path(args.poses)
 
     r = ra.Renderer(args.width, args.height, device=device)
