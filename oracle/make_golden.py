@@ -10,6 +10,11 @@ What is recorded (inputs AND the reference's outputs, as data):
                  radiance for several bounce limits, plus primary-hit (index, t) from the one-line
                  id patch described in oracle/glsl_ref/reference_renderer.py
   texture_*.npz  texture() results of llvmpipe for the noise-texture and cube-map samplers
+  sky_rotation.npz  the tracer's whole sky lookup, texture(u_Skybox, RotateAroundAxis(dir, (1,0,0), -3.1415/2)), run on
+                 llvmpipe with the reference's own RotateAroundAxis (its text is read from the reference's shader at
+                 generation time and compiled into a probe shader; it is not stored): directions in, colours out.
+                 Half of the directions are picked because two algebraically equal forms of the rotation's x component
+                 round differently for them, which moves the looked-up colour by one 8-bit code
   bvh_*.npz      triangles in, (nodes, reordered triangles, material ids) out of the reference's
                  own BvhTree (compiled from its sources into oracle/_ref/libref_host.so)
   loader_*.npz   object files written by us in the reference's formats (tests/golden/objects/), and
@@ -123,6 +128,68 @@ def texture_fixture(gl):
         out["sky_%s_faces" % tag], out["sky_%s_dirs" % tag], out["sky_%s_result" % tag] = faces, dirs, res
     np.savez_compressed(os.path.join(GOLD, "texture_filter.npz"), **out)
     print("texture_filter: done")
+
+
+def sky_rotation_fixture(gl):
+    import re
+    from probe_tex import prog
+    text = open(os.path.join(os.environ.get("RT_REFERENCE_DIR", "/root/reference"), "src", "shaders", "Fragment.glsl")).read()
+    rotate = re.search(r"vec3 RotateAroundAxis\(.*?\n}\n", text, re.S).group(0)
+    W = H = 1024
+    rng = np.random.default_rng(23)
+    sky = scenes.sky_cubemap()
+    p = prog(gl, "#version 430 core\nout vec4 color;\nuniform samplerCube T;\nuniform sampler2D D;\n" + rotate +
+             "void main(){ vec3 d = texelFetch(D, ivec2(gl_FragCoord.xy), 0).xyz;\n"
+             "color = vec4(texture(T, RotateAroundAxis(d, vec3(1.0, 0.0, 0.0), -3.1415/2)).rgb, 1.0); }\n")
+    gl.cubemap(3, sky)
+    gl.u1i(p, "T", 3)
+    t = gl.tex_f32(0, W, H)
+    fb = gl.fbo(t)
+    picked_d, picked_c = [], []
+    for rnd in range(4):
+        dirs = rng.standard_normal((H, W, 4)).astype(f32)
+        n = np.sqrt((dirs[..., :3].astype(np.float64) ** 2).sum(-1, keepdims=True))
+        dirs[..., :3] = (dirs[..., :3] / n).astype(f32)
+        gl.tex_f32(4, W, H, dirs, linear=False)
+        gl.u1i(p, "D", 4)
+        gl.draw(p, fb, W, H)
+        gl.finish()
+        got = gl.read_f32(0, t, W, H)[..., :3].reshape(-1, 3)
+        v = dirs.reshape(-1, 4)[:, :3]
+        # where the unfactored x component, v.x*cos + v.x*(1-cos), differs from v.x*(cos + (1-cos)) in fp32 AND that
+        # changes the colour: found by looking the colour up both ways with the CPU restatement's sampler
+        libm = ctypes.CDLL("libm.so.6")
+        libm.cosf.restype = ctypes.c_float
+        libm.cosf.argtypes = [ctypes.c_float]
+        c = f32(libm.cosf(float(f32(-3.1415 / 2))))
+        x_unfactored = ((v[:, 0] * c).astype(f32) + (v[:, 0] * f32(f32(1) - c)).astype(f32)).astype(f32)
+        cand = np.nonzero(x_unfactored.view(np.uint32) != v[:, 0].view(np.uint32))[0]
+        from rt_oracle import Oracle
+        o = Oracle(8, 8)
+        o.set_skybox(sky)
+        for i in cand:
+            r = o.sample_sky_rotated(v[i])
+            if (r.view(np.uint32) != got[i].view(np.uint32)).any():
+                raise SystemExit("the CPU restatement's sky lookup differs from llvmpipe for direction %r" % (v[i].tolist(),))
+        # sensitive = a one-ulp change of the rotated x moves the colour
+        sens = []
+        y = ((v[:, 1] * c).astype(f32))
+        for i in cand[:60000]:
+            d2 = v[i].copy()
+            d2[0] = x_unfactored[i]
+            # (approximation of "the other form": perturb the input instead of the rotated value; good enough to pick cases)
+            if (o.sample_sky_rotated(d2).view(np.uint32) != got[i].view(np.uint32)).any():
+                sens.append(i)
+        sens = np.array(sens[:1024], dtype=np.int64)
+        plain = rng.integers(0, len(v), 1024)
+        for idx in (sens, plain):
+            picked_d.append(v[idx].copy())
+            picked_c.append(got[idx].copy())
+    dirs = np.concatenate(picked_d)
+    cols = np.concatenate(picked_c)
+    np.savez_compressed(os.path.join(GOLD, "sky_rotation.npz"), dirs=dirs, colours=cols, sky_size=np.int32(sky.shape[1]),
+                        manifest=manifest(gl) + "; sky = scenes.sky_cubemap()")
+    print("sky_rotation: %d directions" % len(dirs))
 
 
 class RefHost:
@@ -274,6 +341,9 @@ def main():
     import tempfile
     tmp = tempfile.mkdtemp()
     gl = GLRef()
+    if "--only-sky-rotation" in sys.argv:
+        sky_rotation_fixture(gl)
+        return
     noise = scenes.noise_texture(64, 48, seed=7)
     sky = scenes.sky_cubemap(32, seed=3)
     cam2 = dict(position=(1.5, -2.0, 0.7), facing=tuple(float(x) for x in (np.array([0.8, 0.55, -0.2], f32) / np.linalg.norm(np.array([0.8, 0.55, -0.2], f32)))),
@@ -290,6 +360,7 @@ def main():
     tracer_fixture(gl, "teapot_small", scene_from(scenes.teapot_like(target_tris=4000), tmp + "/d"), 70, 38, DEFAULT_CAMERA, noise, sky,
                    [(8, 8)])
     texture_fixture(gl)
+    sky_rotation_fixture(gl)
     post_fixture(gl)
     ref = RefHost()
     bvh_fixtures(ref)

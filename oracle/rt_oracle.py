@@ -37,6 +37,7 @@ def _load():
     L.orc_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.orc_sample_noise.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
     L.orc_sample_sky.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_sample_sky_rotated.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     return L
 
 
@@ -119,6 +120,14 @@ class Oracle:
         d = np.ascontiguousarray(d, dtype=np.float32)
         out = np.zeros(3, dtype=np.float32)
         self.L.orc_sample_sky(self.h, d.ctypes.data, out.ctypes.data)
+        return out
+
+
+    def sample_sky_rotated(self, d):
+        """The sky lookup as the tracer makes it: rotation about +x, then the cube map."""
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        out = np.zeros(3, dtype=np.float32)
+        self.L.orc_sample_sky_rotated(self.h, d.ctypes.data, out.ctypes.data)
         return out
 
 

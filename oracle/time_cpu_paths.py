@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Times the two CPU paths on the plumbing configuration (light box, 640x360, 4 bounces, 16 frames), in THIS container:
-the reference shader on Mesa llvmpipe (oracle/_ref/libglref.so; needs /root/reference) and the CPU restatement.
-Also checks that the two images are bit-identical. Test infrastructure, not part of the product.
+"""Times the two CPU paths in THIS container: the reference shader on Mesa llvmpipe (oracle/_ref/libglref.so; needs
+/root/reference) and the CPU restatement, on the plumbing configuration (light box, 640x360, 4 bounces, 16 frames) or
+on a reduced-size sample of another workload. Also checks that the two images are bit-identical. Test
+infrastructure, not part of the product.
 
   python3 oracle/time_cpu_paths.py            (LP_NUM_THREADS is honoured by Mesa; default = all cores)
+  LP_NUM_THREADS=8 python3 oracle/time_cpu_paths.py --scene sponza_like --tris 260000 --width 960 --height 540 \
+      --bounces 8 --frames 4 --json profiles/llvmpipe_recorded.json
 """
+import argparse
+import json
 import os
 import sys
 import time
@@ -22,8 +27,18 @@ from rt_oracle import Oracle  # noqa: E402
 from raytracing_amd import scenes  # noqa: E402
 from util import DEFAULT_CAMERA, differing_pixels, make_scene  # noqa: E402
 
-W, H, BL, FRAMES = 640, 360, 4, 16
-sc = make_scene("lightbox")
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="lightbox")
+ap.add_argument("--tris", type=int, default=0)
+ap.add_argument("--width", type=int, default=640)
+ap.add_argument("--height", type=int, default=360)
+ap.add_argument("--bounces", type=int, default=4)
+ap.add_argument("--frames", type=int, default=16)
+ap.add_argument("--workload", default="", help="name of the bench.py workload this is a sample of (recorded in --json)")
+ap.add_argument("--json", default="", help="write the figures to this file")
+args = ap.parse_args()
+W, H, BL, FRAMES = args.width, args.height, args.bounces, args.frames
+sc = make_scene(args.scene, **({"target_tris": args.tris} if args.tris else {}))
 noise, sky, seeds = scenes.noise_texture(), scenes.sky_cubemap(), scenes.frame_seeds(FRAMES + 1)
 threads = os.cpu_count() or 1
 
@@ -54,8 +69,17 @@ o.render(1, seeds[1:])
 t_orc = (time.perf_counter() - t0) / FRAMES
 rays = o.counters()["rays"]
 b = o.read_accum()
-print("light box %dx%d, bounce limit %d, %d frames after one warm-up frame, %d host threads (LP_NUM_THREADS=%s)" % (
-    W, H, BL, FRAMES, threads, os.environ.get("LP_NUM_THREADS", "unset")))
+print("%s (%d triangles) %dx%d, bounce limit %d, %d frames after one warm-up frame, %d host threads (LP_NUM_THREADS=%s)" % (
+    args.scene, sc.n_triangles, W, H, BL, FRAMES, threads, os.environ.get("LP_NUM_THREADS", "unset")))
 print("llvmpipe (reference shader): %.2f ms/frame  %.2f Mrays/s" % (t_ref * 1e3, rays / FRAMES / t_ref / 1e6))
 print("CPU restatement (oracle):    %.2f ms/frame  %.2f Mrays/s" % (t_orc * 1e3, rays / FRAMES / t_orc / 1e6))
 print("pixels differing between the two after %d frames: %d" % (FRAMES + 1, differing_pixels(a, b)))
+if args.json:
+    json.dump({"workload": args.workload, "scene": args.scene, "triangles": sc.n_triangles, "resolution": [W, H], "bounce_limit": BL,
+               "frames_timed": FRAMES, "host_cores": threads, "LP_NUM_THREADS": os.environ.get("LP_NUM_THREADS", "unset (all cores)"),
+               "renderer": ref.gl.renderer_string() if hasattr(ref.gl, "renderer_string") else "llvmpipe (Mesa 23.2.1, LLVM 15.0.7)",
+               "llvmpipe_mrays_per_s": round(rays / FRAMES / t_ref / 1e6, 3), "llvmpipe_ms_per_frame": round(t_ref * 1e3, 2),
+               "cpu_restatement_mrays_per_s": round(rays / FRAMES / t_orc / 1e6, 3), "cpu_restatement_ms_per_frame": round(t_orc * 1e3, 2),
+               "rays_per_frame": rays // FRAMES, "images_bit_identical": differing_pixels(a, b) == 0,
+               "where": "build container (no GPU); the reference shader text cannot travel to the GPU box",
+               "note": "first frame (LLVM JIT of the shader) excluded"}, open(args.json, "w"), indent=1)

@@ -170,6 +170,9 @@ __device__ __forceinline__ void coord_clamp(float c, int n, int& i0, int& i1, in
 __device__ __forceinline__ Texels fetch_sky(const SceneParams& sp, V3 dir) {
     const V3 k = mk(1.0f, 0.0f, 0.0f);
     V3 d = (dir * sp.skyCos + cross3(k, dir) * sp.skySin) + (k * dot3(k, dir)) * (1.0f - sp.skyCos);
+    // With the axis a constant, the shader compiler in front of llvmpipe factors the x component,
+    // dir.x * cos + dir.x * (1 - cos), into dir.x * (cos + (1 - cos)); the two differ in the last bit now and then.
+    d.x = dir.x * (sp.skyCos + (1.0f - sp.skyCos));
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     int axis = (az >= fmaxf(ax, ay)) ? 2 : (ax > ay ? 0 : 1);
     float ma = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);

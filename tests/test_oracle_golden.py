@@ -92,3 +92,17 @@ def test_texture_filters_match_llvmpipe():
         for d, want in zip(t["sky_%s_dirs" % tag], t["sky_%s_result" % tag]):
             bad += int((bits(o.sample_sky(d)) != bits(want)).any())
         assert bad == 0, (tag, bad)
+
+
+def test_rotated_sky_lookup_matches_llvmpipe():
+    """The tracer's whole sky lookup (rotation about +x, then the cube map: Fragment.glsl:158-163,406,411) against
+    llvmpipe running the reference's own RotateAroundAxis. The fixture holds directions for which two algebraically
+    equal forms of the rotation round differently (the shader compiler in front of llvmpipe factors the x component)."""
+    from raytracing_amd import scenes
+    t = np.load(os.path.join(GOLDEN, "sky_rotation.npz"))
+    sky = scenes.sky_cubemap()
+    assert sky.shape[1] == int(t["sky_size"])
+    o = Oracle(8, 8)
+    o.set_skybox(sky)
+    bad = sum(int((bits(o.sample_sky_rotated(d)) != bits(want)).any()) for d, want in zip(t["dirs"], t["colours"]))
+    assert len(t["dirs"]) > 4000 and bad == 0, bad
