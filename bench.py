@@ -31,6 +31,12 @@ import raytracing_amd as ra  # noqa: E402
 from raytracing_amd import scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, 8 TB/s
+# Ceilings of the units this kernel actually loads (the scene is cache-resident, so HBM is not one of them):
+SIMDS, CUS = 1024, 256
+ISSUE_CYCLES_PER_INSTRUCTION = 2.2    # one wave64 instruction of any kind per SIMD, measured: tools/microbench/valu_rate.hip
+L1_ACCESSES_PER_CYCLE_PER_CU = 1.48   # 16-byte lane accesses of a gather the vector L1 serves, measured: tools/microbench/l1_gather.hip
+L2_PEAK_GBS = 34500.0                 # aggregate L2 bandwidth of the 8 XCDs
+L2_BYTES_PER_REQUEST = 128            # a vector-L1 line
 
 WORKLOADS = {
     # name: (scene generator, kwargs, width, height, bounce limit)
@@ -47,6 +53,59 @@ def algorithmic_bytes(c):
     16 B per sky fetch (4 RGBA8 texels), 32 B framebuffer traffic per pixel sample."""
     return (32 * c["boxes_tested"] + 48 * c["tris_tested"] + 4 * c["hits"] + 12 * c["noise_fetches"] +
             16 * c["sky_fetches"] + 32 * c["paths"])
+
+
+def binding_roofs(workload, avg_ms):
+    """The ceilings that do bound the kernel, each as achieved / peak with the peak's source. The numerators that
+    need hardware counters (instructions, cache accesses per launch) come from the committed rocprofv3 summary of this
+    same command (profiles/counters.json, written by tools/profile_bench.sh + tools/summarize_prof.py); the
+    denominator is this run's own kernel time, and the shader clock is the profile's cycles over the profile's time."""
+    cf = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(cf):
+        return {}
+    with open(cf) as f:
+        c = json.load(f)
+    if c.get("workload") != workload or not c.get("kernel_ms_when_profiled"):
+        return {}
+    clock_hz = c["shader_cycles_per_launch"] / (c["kernel_ms_when_profiled"] * 1e-3)
+    sec = avg_ms * 1e-3
+    roofs = []
+    issue_peak = SIMDS * clock_hz / ISSUE_CYCLES_PER_INSTRUCTION / 1e9
+    issue = c["instructions_per_launch"] / sec / 1e9
+    roofs.append({"name": "instruction issue", "achieved": round(issue, 1), "peak": round(issue_peak, 1), "unit": "G wave-instructions/s",
+                  "frac": round(issue / issue_peak, 4),
+                  "peak_source": "1024 SIMDs x %.2f GHz / 2.2 cycles per wave64 instruction of any kind (tools/microbench/valu_rate.hip)" % (clock_hz / 1e9)})
+    l1_peak = CUS * clock_hz * L1_ACCESSES_PER_CYCLE_PER_CU / 1e9
+    l1 = c["vector_l1_accesses_per_launch"] / sec / 1e9
+    roofs.append({"name": "vector L1 / texture-address path", "achieved": round(l1, 1), "peak": round(l1_peak, 1), "unit": "G lane accesses/s",
+                  "frac": round(l1 / l1_peak, 4),
+                  "peak_source": "256 CUs x %.2f GHz x 1.48 accesses per cycle and CU reached by a 16-byte gather (tools/microbench/l1_gather.hip)" % (clock_hz / 1e9)})
+    if c.get("l2_requests_per_launch"):
+        l2 = c["l2_requests_per_launch"] * L2_BYTES_PER_REQUEST / sec / 1e9
+        roofs.append({"name": "L2", "achieved": round(l2, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_PEAK_GBS, 4),
+                      "peak_source": "aggregate L2 bandwidth, 34.5 TB/s; bytes = TCC_REQ x 128 (a vector-L1 line; uncalibrated, an upper bound)"})
+    binding = max(roofs, key=lambda r: r["frac"])
+    return {"roofs": roofs, "binding_roof": {k: binding[k] for k in ("name", "achieved", "peak", "unit", "frac")},
+            "counters": {k: c.get(k) for k in ("profile", "source", "instructions_per_launch", "shader_cycles_per_launch", "vector_l1_accesses_per_launch",
+                                                "l2_hit_rate", "vector_l1_hit_rate", "valu_lane_utilisation", "mean_waves_per_simd",
+                                                "wave_time_waiting", "ta_busy", "kernel_ms_when_profiled")}}
+
+
+def llvmpipe_recorded(workload):
+    """The reference shader on Mesa llvmpipe for this workload's scene, as recorded in the build container (the shader
+    text cannot travel to the GPU box, so it cannot be timed in this run)."""
+    lf = os.path.join(ROOT, "profiles", "llvmpipe_recorded.json")
+    if not os.path.exists(lf):
+        return None
+    with open(lf) as f:
+        r = json.load(f)
+    if r.get("workload") != workload:
+        return None
+    return {"value": r["llvmpipe_mrays_per_s"], "unit": "Mrays/s", "cores": r["host_cores"], "LP_NUM_THREADS": r["LP_NUM_THREADS"],
+            "renderer": r["renderer"], "where": r["where"],
+            "sample": "same scene, camera and bounce limit at %dx%d, %d frames after the JIT frame (%.0f ms/frame); the CPU restatement on the same "
+                      "cores and sample: %.2f Mrays/s, images bit-identical: %s" % (r["resolution"][0], r["resolution"][1], r["frames_timed"],
+                                                                                   r["llvmpipe_ms_per_frame"], r["cpu_restatement_mrays_per_s"], r["images_bit_identical"])}
 
 
 def load_workload(name, threads):
@@ -106,8 +165,8 @@ def cpu_baseline(sc, noise, sky, bl, W, H):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="sponza_like_3840x2160_b8", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the instrumented replay that measures algorithmic bytes")
@@ -275,8 +334,9 @@ def main():
                 traffic = t.get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "note": "algorithmic bytes (what the reference shader fetches) are mostly cache hits here: frac > 1 means the "
-                            "kernel is not HBM-bound; 'traffic' is the measured memory-side bytes per launch",
+                    "note": "algorithmic bytes (what the reference shader fetches) are re-reads served by L1/L2/Infinity Cache here (the scene is "
+                            "cache-resident): frac > 1 means HBM does not bound this kernel; 'traffic' is the measured memory-side bytes per launch; "
+                            "the roofs that do bind are under 'roofs', the nearest one under 'binding_roof'",
                     "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 4),
                     "algorithmic_bytes_per_launch": int(per_launch),
                     "bytes_per_ray": round(algorithmic_bytes(ci) / ci["rays"], 1),
@@ -286,6 +346,7 @@ def main():
                     "rounds_new_interior_leaf_shade": [n // launches for n in ci["sched_rounds"]],
                     "wave_cycles_per_round_new_interior_leaf_shade": [round(64.0 * c / max(1, n)) for c, n in zip(ci["sched_cycles"], ci["sched_rounds"])],
                     "wave_time_share_new_interior_leaf_shade": [round(c / max(1, sum(ci["sched_cycles"])), 3) for c in ci["sched_cycles"]]}
+        roofline.update(binding_roofs(args.workload, avg_ms))
 
     if rank == 0:
         out = {
@@ -303,6 +364,9 @@ def main():
             out["roofline"] = roofline
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(sc, noise, sky, bl, W, H)
+        rec = llvmpipe_recorded(args.workload)
+        if rec and not sharded:
+            out["llvmpipe_recorded"] = rec
         print(json.dumps(out), flush=True)
     if sharded:
         dist.barrier()

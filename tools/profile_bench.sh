@@ -6,7 +6,8 @@ TAG=${1:-r01}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline-pass $@"
+# bench.py with its default step counts: the counters then describe the launches the bench line times
+ARGS="--no-cpu-baseline --no-roofline-pass $@"
 python3 bench.py $ARGS > $OUT/plain.json 2> $OUT/plain.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
 i=0

@@ -9,7 +9,19 @@ import sys
 
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", "prof_" + tag)
-lines = ["# rocprofv3 summary for tag %s (command: python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline-pass %s)" % (tag, " ".join(sys.argv[2:])), ""]
+lines = ["# rocprofv3 summary for tag %s (command: python3 bench.py --no-cpu-baseline --no-roofline-pass %s)" % (tag, " ".join(sys.argv[2:])), ""]
+plain = json.loads(open(os.path.join(src, "plain.json")).read().strip().splitlines()[-1])
+WARMUP = int(plain.get("warmup", 0))
+
+
+def timed_rows(path):
+    """Counter rows of the trace_kernel dispatches the bench line times: the first `warmup` dispatches are dropped."""
+    rows = [r for r in csv.DictReader(open(path)) if "trace_kernel" in r["Kernel_Name"]]
+    ids = sorted(set(int(r["Dispatch_Id"]) for r in rows))
+    keep = set(ids[WARMUP:]) if len(ids) > WARMUP else set(ids)
+    return [r for r in rows if int(r["Dispatch_Id"]) in keep]
+
+
 lines.append("## bench line of the un-profiled run")
 lines.append(open(os.path.join(src, "plain.json")).read().strip())
 lines.append("")
@@ -17,9 +29,9 @@ lines.append("## rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     lines.append(open(f).read().strip())
 lines.append("")
-lines.append("## PMC passes (separate runs, one per counter group): per-dispatch mean over the trace_kernel dispatches")
+lines.append("## PMC passes (separate runs, one per counter group): per-dispatch mean over the timed trace_kernel dispatches (warm-up dispatches dropped)")
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
-    rows = [r for r in csv.DictReader(open(f)) if "trace_kernel" in r["Kernel_Name"]]
+    rows = timed_rows(f)
     if not rows:
         continue
     n = len(set(r["Dispatch_Id"] for r in rows))
@@ -34,7 +46,7 @@ for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.c
         lines.append("    %-34s %.6g" % (k, v / n))
 v = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
-    rows = [r for r in csv.DictReader(open(f)) if "trace_kernel" in r["Kernel_Name"]]
+    rows = timed_rows(f)
     n = max(1, len(set(r["Dispatch_Id"] for r in rows)))
     here = collections.defaultdict(float)
     for r in rows:
@@ -71,6 +83,29 @@ if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                "note": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 per trace_kernel dispatch; memory-side L2 requests, Infinity-Cache hits included"}
     json.dump(traffic, open(os.path.join("profiles", "hbm_traffic.json"), "w"), indent=1)
     lines.append("memory-side traffic    = %.3f GB per dispatch (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes)" % ((fetch + write) / 1e9))
+# The counters bench.py carries into its roofline object (per trace_kernel launch, means over the profiled dispatches).
+need = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE", "TCP_TOTAL_CACHE_ACCESSES_sum")
+if all(k in v for k in need):
+    bench = json.loads(open(os.path.join(src, "plain.json")).read().strip().splitlines()[-1])
+    insts = sum(v[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD")) + v.get("SQ_INSTS_VMEM_WR", 0.0) + v.get("SQ_INSTS_SMEM", 0.0)
+    cycles = v["GRBM_GUI_ACTIVE"] / 8.0          # the counter is summed over the 8 XCDs
+    c = {"workload": bench["config"]["workload"], "profile": tag,
+         "source": "rocprofv3 --pmc passes of tools/profile_bench.sh, condensed by tools/summarize_prof.py into profiles/%s_summary.txt" % tag,
+         "instructions_per_launch": int(insts), "valu_instructions_per_launch": int(v["SQ_INSTS_VALU"]),
+         "shader_cycles_per_launch": int(cycles),
+         "vector_l1_accesses_per_launch": int(v["TCP_TOTAL_CACHE_ACCESSES_sum"]),
+         "l1_to_l2_read_requests_per_launch": int(v.get("TCP_TCC_READ_REQ_sum", 0)),
+         "l2_requests_per_launch": int(v.get("TCC_REQ_sum", 0)),
+         "l2_hit_rate": round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v else None,
+         "vector_l1_hit_rate": round(1 - v["TCP_TCC_READ_REQ_sum"] / v["TCP_TOTAL_CACHE_ACCESSES_sum"], 4) if "TCP_TCC_READ_REQ_sum" in v else None,
+         "valu_lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64), 4) if "SQ_THREAD_CYCLES_VALU" in v else None,
+         "mean_waves_per_simd": round(4 * v["SQ_WAVE_CYCLES"] / (cycles * 1024), 3) if "SQ_WAVE_CYCLES" in v else None,
+         "wave_time_waiting": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_ANY" in v else None,
+         "ta_busy": round(v["TA_TA_BUSY_sum"] / (cycles * 256), 4) if "TA_TA_BUSY_sum" in v else None,
+         "kernel_ms_when_profiled": bench["config"].get("trace_kernel_ms_per_step")}
+    json.dump(c, open(os.path.join("profiles", "counters.json"), "w"), indent=1)
+    lines.append("instructions / launch  = %.4g (vector %.4g) in %.4g shader cycles: issue load %.3f of one instruction per 2.2 cycles and SIMD" % (
+        insts, v["SQ_INSTS_VALU"], cycles, insts * 2.2 / (1024 * cycles)))
 out = os.path.join("profiles", tag + "_summary.txt")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[-12:]))
