@@ -20,8 +20,7 @@ namespace rtd {
 void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames, const FrameParams* single, uint32_t* queueHeads);
 void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
                  void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
-                 const uint32_t* order, uint32_t* tileCost, void* poolArea);
-size_t PoolBytesPerGroup();
+                 const uint32_t* order, uint32_t* tileCost);
 void LaunchOrderKeys(hipStream_t st, uint32_t* tileCost, uint32_t* keys, uint32_t* vals, uint32_t nTiles);
 uint32_t SpillEntriesPerWave();
 uint32_t ResidentWaves();
@@ -65,8 +64,6 @@ struct rt_context {
     FrameStage stage[4]; uint32_t stageNext = 0;
     uint32_t* dTally = nullptr;      // [kCounterSlots][maxWaves]
     void* dSpill = nullptr;          // stack spill area, maxWaves * SpillEntriesPerWave() * 8 bytes
-    void* dPool = nullptr;           // ray pool of the pooled scheduler, one block per work-group of the persistent grid
-    bool usePool = false;
     uint32_t* dQueue = nullptr;      // 64 words; the first 8 are the per-band tile counters
     // tile hand-out order: rays traced per tile since the last re-ordering, and the order derived from them
     uint32_t* dTileCost = nullptr;   // [shardTiles]
@@ -212,11 +209,6 @@ int rt_create(int device, uint32_t width, uint32_t height, rt_context** out) {
         if (me == hipSuccess) me = hipMemsetAsync(c->dTally, 0, tb, c->stream);
         if (me == hipSuccess) me = hipMalloc(&c->dSpill, (size_t)c->maxWaves * SpillEntriesPerWave() * 8);
         if (me == hipSuccess) me = hipMalloc((void**)&c->dQueue, 256);
-        if (me == hipSuccess) me = hipMalloc(&c->dPool, (size_t)((c->maxWaves + 3) / 4) * PoolBytesPerGroup());
-        {   // RT_SCHEDULER=wave selects the one-ray-per-lane scheduler (kernel-tuning experiments; both give the same images)
-            const char* e = std::getenv("RT_SCHEDULER");
-            c->usePool = !(e && std::strcmp(e, "wave") == 0);
-        }
         if (me == hipSuccess) me = hipMalloc((void**)&c->dFrames, sizeof(FrameParams) * 64);
         if (me == hipSuccess) c->framesCap = 64;
         if (me != hipSuccess) rc = Fail(c, RT_ERR_DEVICE, "rt_create: %s", hipGetErrorString(me));
@@ -235,7 +227,7 @@ void rt_destroy(rt_context* c) {
     for (auto& pr : c->freeEvents) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     FreePostprocess(&c->postScratch);
     for (auto& sg : c->stage) { if (sg.host) (void)hipHostFree(sg.host); if (sg.copied) (void)hipEventDestroy(sg.copied); }
-    void* ptrs[] = {c->dNodes, c->dTris, c->dNoise, c->dSky, c->dMaterials, c->dAccum, c->dLinear, c->dFrames, c->dTally, c->dTotals, c->dIds, c->dSpill, c->dPool, c->dQueue,
+    void* ptrs[] = {c->dNodes, c->dTris, c->dNoise, c->dSky, c->dMaterials, c->dAccum, c->dLinear, c->dFrames, c->dTally, c->dTotals, c->dIds, c->dSpill, c->dQueue,
                     c->dTileCost, c->dOrderKeys, c->dOrderVals, c->dSortTemp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -485,7 +477,7 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
     const bool reorderAfter = !ids && ((k & (k - 1)) == 0 || (k & 7u) == 0);
     const uint32_t* order = (c->orderValid && !ids) ? c->dOrderVals + c->sp.shardTiles : nullptr;
     LaunchTrace(count, ids, c->stream, nWaves, c->sp, c->dFrames, nFrames, c->dAccum, c->dTally, c->maxWaves, c->dIds, c->dSpill, c->dQueue, nGroups,
-                order, reorderAfter ? c->dTileCost : nullptr, c->usePool ? c->dPool : nullptr);
+                order, reorderAfter ? c->dTileCost : nullptr);
     HIP_TRY(c, hipGetLastError());
     if (!ids) {
         c->launchesSinceAlloc = k;

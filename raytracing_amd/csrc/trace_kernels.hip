@@ -783,496 +783,6 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
     }
 }
 
-
-// =====================================================================================================================
-// Pooled scheduler: the same per-ray arithmetic, with rays regrouped inside the work-group.
-//
-// In trace_kernel above a ray lives in one lane from its pixel's first frame to its last, and a wave runs the
-// material code with whatever share of its lanes happens to wait for it (0.44 measured), while lanes that wait
-// idle through the interior-node rounds (0.63). Here a ray is a record in a per-group pool in memory (its path
-// state and its origin/direction), a lane holds only the traversal of the ray it is tracing, and two rings of ray
-// numbers in LDS connect the two kinds of work:
-//   * shade ring: rays whose traversal is over. Any wave that finds 64 of them (or fewer when it has nothing else
-//     to do) shades them in one round with all lanes busy, whatever wave traced them, and writes the continued ray
-//     (or the pixel's next frame, or the next pixel from the group's tile) back to the pool;
-//   * trace ring: rays waiting for a lane. A wave that has a few free lanes hands their results in and takes new
-//     rays in one short exchange round, so the lanes of the long interior-node loop stay filled.
-// Rays never leave their work-group (one CU): the hand-over needs no cross-CU visibility. Pool records are written
-// with plain stores, completed (s_waitcnt vmcnt(0)) before the ray number is pushed into a ring, and read with sc1
-// loads, which are served by L2 and cannot return a line the CU's L1 kept from the ray's previous segment.
-// Per-pixel results are the same bits as trace_kernel's: what is computed for a ray does not depend on the lane.
-// =====================================================================================================================
-#ifndef RT_POOL_RAYS
-#define RT_POOL_RAYS 384           // rays alive per work-group: 256 lanes + what waits in the rings
-#endif
-#ifndef RT_XCHG_AT
-#define RT_XCHG_AT 12              // run the exchange round once this many lanes have a result to hand in or are free
-#endif
-constexpr uint32_t kPoolRays = RT_POOL_RAYS;
-constexpr uint32_t kRingCap = 1024;         // entries per ring: more than kPoolRays + 4 x 64 (claimed, not yet read), power of two
-constexpr uint32_t kFresh = 0x8000u;        // shade-ring entry of a ray slot that has no pixel yet
-static_assert(kRingCap >= kPoolRays + 4 * 64 && (kRingCap & (kRingCap - 1)) == 0 && kPoolRays < 0x7fff, "ring too small");
-constexpr uint32_t kPoolCtrlWords = 16;
-constexpr size_t kPoolLdsFixed = (size_t)kWgWaves * kLdsStack * 512 + sizeof(MaterialRec) * kMaxMaterials + 2 * kRingCap * 2 + kPoolCtrlWords * 4;
-static_assert(kPoolLdsFixed < kLdsPerGroup, "no LDS left for the pooled scheduler");
-constexpr uint32_t kPoolTopLds = (uint32_t)((kLdsPerGroup - kPoolLdsFixed) / sizeof(NodeRec));   // tree-top records that still fit
-static_assert(kPoolTopLds <= kTopRecords, "the LDS copy must lie within the breadth-first part of the node array");
-enum PoolCtrl { kShadeReserve = 0, kShadeHead, kTraceReserve, kTraceHead, kLive, kPixelPool };
-// kPixelPool: the group's current tile, shared by its waves: (local tile << 7) | pixels handed out; 126 = a wave is
-// fetching the next tile, 127 = no tiles left.
-constexpr uint32_t kPoolRefilling = 126u, kPoolExhausted = 127u;
-
-// One ray of the pool. a, b.xy, c, d, e.xy are written by the wave that shades; b.zw and e.z by the lane that traced.
-struct alignas(16) PoolRec {
-    float4 a;        // origin, direction.x
-    float4 b;        // direction.y, direction.z, hit distance, hit triangle (bits)
-    float4 c;        // running mean of the pixel, pixel slot (bits)
-    float4 d;        // throughput, frame counter within the launch (bits)
-    uint4 e;         // bounce counter, segments of the path, iterationsCount, unused
-};
-static_assert(sizeof(PoolRec) == 80, "pool record size");
-
-typedef float Float4v __attribute__((ext_vector_type(4)));
-// 16 bytes from memory through L2 (sc1: not from this CU's L1). The value is valid after pool_wait().
-__device__ __forceinline__ Float4v load16_l2(const void* p) {
-    Float4v v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void pool_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void pool_wait(Float4v& a, Float4v& b) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b)::"memory"); }
-__device__ __forceinline__ void pool_wait(Float4v& a, Float4v& b, Float4v& c, Float4v& d, Float4v& e) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)::"memory");
-}
-
-__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// (LDS-qualified: with generic pointers these volatile accesses become FLAT instructions)
-typedef __attribute__((address_space(3))) uint16_t LdsU16;
-
-// Appends `value` of every lane with `want` to a ring (all lanes of the wave call this together).
-__device__ __forceinline__ void ring_push(volatile LdsU16* ring, uint32_t* reserve, bool want, uint32_t value, uint32_t lane) {
-    const unsigned long long m = __ballot(want);
-    if (m == 0ull) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(reserve, (uint32_t)__popcll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (want) ring[(base + rank) & (kRingCap - 1u)] = (uint16_t)value;
-}
-
-// Takes up to maxN entries (none when fewer than minN are there) off a ring: returns how many, and the position of the
-// first. All lanes call this together; entries may still be on their way into the ring: see ring_take.
-__device__ __forceinline__ uint32_t ring_claim(uint32_t* reserve, uint32_t* head, uint32_t maxN, uint32_t minN, uint32_t lane, uint32_t& base) {
-    uint32_t n = 0, b = 0;
-    if (lane == 0 && maxN != 0u) {
-        for (;;) {
-            const uint32_t h = lds_load(head), avail = lds_load(reserve) - h;
-            const uint32_t take = min(avail, maxN);
-            if (take == 0u || take < minN) break;
-            if (atomicCAS(head, h, h + take) == h) { b = h; n = take; break; }
-        }
-    }
-    base = __builtin_amdgcn_readfirstlane(b);
-    return __builtin_amdgcn_readfirstlane(n);
-}
-// The entry at `pos`, taken out of the ring. A producer reserves its positions first and writes them next, so a
-// claimed entry may be a few cycles away: wait for it (the producer is a running wave of this group; it is never
-// waiting for us).
-__device__ __forceinline__ uint32_t ring_take(volatile LdsU16* ring, uint32_t pos) {
-    volatile LdsU16* e = ring + (pos & (kRingCap - 1u));
-    uint32_t v = *e;
-    while (v == 0u) { __builtin_amdgcn_s_sleep(1); v = *e; }
-    *e = 0;
-    return v;
-}
-
-template <bool COUNT, bool IDS, bool SINGLE, bool ITERS>
-__global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_pool_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
-                                                   float4* __restrict__ accum, uint32_t* __restrict__ tally, int32_t* __restrict__ ids,
-                                                   uint2* __restrict__ spillArea, uint32_t* __restrict__ queueHeads, uint32_t nGroups, uint32_t tallyStride,
-                                                   const uint32_t* __restrict__ order, uint32_t* __restrict__ tileCost,
-                                                   PoolRec* __restrict__ poolArea /* [gridDim.x][kPoolRays] */) {
-    __shared__ uint2 lds_stack[kWgWaves * kLdsStack * 64];
-    __shared__ MaterialRec lds_mat[kMaxMaterials];
-    __shared__ uint16_t lds_shade[kRingCap];
-    __shared__ uint16_t lds_trace[kRingCap];
-    __shared__ uint32_t ctrl[kPoolCtrlWords];
-    __shared__ Words4 lds_top[kPoolTopLds > 0 ? kPoolTopLds * 4 : 1];
-    const uint32_t lane = threadIdx.x & 63u, waveInGroup = threadIdx.x >> 6;
-    const uint32_t wave = blockIdx.x * (uint32_t)kWgWaves + waveInGroup;
-    const uint32_t nTop = min(kPoolTopLds, sp.nInterior);
-    StackRef st;
-    st.lds = lds_stack + waveInGroup * (uint32_t)(kLdsStack * 64) + lane;
-    st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)wave * (kMaxStack - kLdsStack) * 64;
-    st.lane = lane;
-    st.top = (const LdsWords4*)lds_top;
-    st.topBytes = nTop * (uint32_t)sizeof(NodeRec);
-    st.lds[0] = make_uint2(kNoRef, __float_as_uint(-INFINITY));
-    for (uint32_t j = threadIdx.x; j < (uint32_t)(sizeof(MaterialRec) / 4 * kMaxMaterials); j += blockDim.x)
-        reinterpret_cast<uint32_t*>(lds_mat)[j] = reinterpret_cast<const uint32_t*>(sp.materials)[j];
-    for (uint32_t j = threadIdx.x; j < nTop * 4u; j += blockDim.x) lds_top[j] = reinterpret_cast<const Words4*>(sp.nodes)[j];
-    for (uint32_t j = threadIdx.x; j < kRingCap; j += blockDim.x) { lds_shade[j] = 0; lds_trace[j] = 0; }
-    if (threadIdx.x < kPoolCtrlWords) ctrl[threadIdx.x] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) { ctrl[kLive] = kPoolRays; ctrl[kPixelPool] = 64u; }      // every slot counts as alive until it fails to get a pixel
-    __syncthreads();
-    PoolRec* const pool = poolArea + (size_t)blockIdx.x * kPoolRays;
-    volatile LdsU16* const shadeRing = (volatile LdsU16*)lds_shade;
-    volatile LdsU16* const traceRing = (volatile LdsU16*)lds_trace;
-
-    const uint32_t BL = sp.bounceLimit;
-    const V3 camPos = mk(sp.camPos[0], sp.camPos[1], sp.camPos[2]);
-    const V3 facing = mk(sp.camFacing[0], sp.camFacing[1], sp.camFacing[2]);
-    const float resx = uni((float)sp.width), resy = uni((float)sp.height);
-    const float nresx = uni((float)sp.noiseW), nresy = uni((float)sp.noiseH);
-    const float rTilesX = uni(1.0f / (float)sp.tilesX);
-    const float rresx = uni(1.0f / resx), rresy = uni(1.0f / resy), rnresx = uni(1.0f / nresx), rnresy = uni(1.0f / nresy);
-    const float vpH = uni(sp.vpW * (resy / resx));
-    const V3 U = uni3(normalize3(cross3(facing, mk(0.0f, 0.0f, 1.0f))));
-    const V3 Vd = uni3(normalize3(cross3(U, facing)));
-    const uint32_t nTiles = sp.tilesX * sp.tilesY;
-    FrameParams f0 = {};
-    if (SINGLE) f0 = frames[0];
-    const uint32_t bandSize = (nGroups + 7u) / 8u;
-    uint32_t band = blockIdx.x % 8u, bandsTried = 0;      // tile queue cursor (used by lane 0 when it fetches a tile for the group)
-
-    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    RoundClock rc = {0ull, {0ull, 0ull, 0ull, 0ull}};
-    Lane L;
-    L.state = kIdle; L.slot = 0; L.k = 0; L.bounce = 0; L.segments = 0; L.cur = kNoRef; L.top = 0;
-    L.bestT = INFINITY; L.bestIdx = -1; L.iters = 0;
-    L.previous = mk(0.f, 0.f, 0.f); L.throughput = mk(1.f, 1.f, 1.f);
-    L.ray.o = L.ray.d = L.ray.inv = mk(0.f, 0.f, 0.f);
-    uint32_t rid = 0;                                       // pool slot of the ray this lane is tracing
-
-    // every ray slot of the group starts as a request for a pixel: this wave's share goes into the shade ring
-    for (uint32_t first = waveInGroup * 64u; first < kPoolRays; first += (uint32_t)kWgWaves * 64u) {
-        const uint32_t r = first + lane;
-        ring_push(shadeRing, &ctrl[kShadeReserve], r < kPoolRays, (r + 1u) | kFresh, lane);
-    }
-
-    for (;;) {
-        const int nInt = __popcll(__ballot(at_interior(L.cur)));
-        const int nLeaf = __popcll(__ballot(at_leaf(L.cur)));
-        const bool finished = awaits_shading(L.state, L.cur);
-        const int nDone = __popcll(__ballot(finished));
-        const int nFree = __popcll(__ballot(L.state == kIdle));
-        const uint32_t shadeAvail = lds_load(&ctrl[kShadeReserve]) - lds_load(&ctrl[kShadeHead]);
-        const uint32_t traceAvail = lds_load(&ctrl[kTraceReserve]) - lds_load(&ctrl[kTraceHead]);
-        const int busy = nInt + nLeaf;
-        const bool runExchange = nDone >= RT_XCHG_AT || (nDone + nFree >= RT_XCHG_AT && traceAvail != 0u) ||
-                                 (busy == 0 && (nDone != 0 || (nFree != 0 && traceAvail != 0u)));
-        const bool runShade = !runExchange && (shadeAvail >= 64u || (shadeAvail != 0u && busy == 0));
-
-        if (COUNT) rc.start();
-        if (runExchange) {
-            // ================= exchange round: results out, new rays in =================
-            if (COUNT) { tl.rounds[0] += (lane == 0); tl.lanes[0] += finished; }
-            if (finished) {
-                if (COUNT) tl.pops += (uint32_t)L.iters;
-                *reinterpret_cast<float2*>(&pool[rid].b.z) = make_float2(L.bestT, __int_as_float(L.bestIdx));
-                if (ITERS) pool[rid].e.z = (uint32_t)L.iters;
-            }
-            const bool wantRay = finished || L.state == kIdle;
-            const unsigned long long wantMask = __ballot(wantRay);
-            uint32_t base;
-            const uint32_t got = ring_claim(&ctrl[kTraceReserve], &ctrl[kTraceHead], (uint32_t)__popcll(wantMask), 1u, lane, base);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(wantMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wantMask, 0u));
-            const bool take = wantRay && rank < got;
-            uint32_t newRid = 0;
-            Float4v ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
-            if (take) {
-                newRid = ring_take(traceRing, base + rank) - 1u;
-                ra = load16_l2(&pool[newRid].a);
-                rb = load16_l2(&pool[newRid].b);
-            }
-            pool_wait(ra, rb);                                  // the new rays have arrived, and the results stored above are in L2
-            ring_push(shadeRing, &ctrl[kShadeReserve], finished, rid + 1u, lane);
-            if (finished) L.state = kIdle;
-            if (take) {
-                rid = newRid;
-                L.ray = MakeRay(mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y));
-                begin_traversal<COUNT, ITERS>(sp, L, tl);
-            }
-            if (COUNT) rc.stop(0);
-        } else if (runShade) {
-            // ================= shading round: up to 64 finished rays of any wave of the group =================
-            uint32_t base;
-            const uint32_t n = ring_claim(&ctrl[kShadeReserve], &ctrl[kShadeHead], 64u, 1u, lane, base);
-            const bool active = lane < n;
-            if (COUNT) { tl.rounds[3] += (lane == 0); tl.lanes[3] += active; }
-            uint32_t srid = 0;
-            bool fresh = false;
-            Float4v pa = {0.f, 0.f, 0.f, 0.f}, pb = pa, pc = pa, pd = pa, pe = pa;
-            if (active) {
-                const uint32_t e = ring_take(shadeRing, base + lane);
-                fresh = (e & kFresh) != 0u;
-                srid = (e & (kFresh - 1u)) - 1u;
-                if (!fresh) {
-                    pa = load16_l2(&pool[srid].a); pb = load16_l2(&pool[srid].b); pc = load16_l2(&pool[srid].c);
-                    pd = load16_l2(&pool[srid].d); pe = load16_l2(&pool[srid].e);
-                }
-            }
-            pool_wait(pa, pb, pc, pd, pe);
-            // the ray as it was traced, and its path's state
-            Ray ray;
-            ray.o = mk(pa.x, pa.y, pa.z); ray.d = mk(pa.w, pb.x, pb.y); ray.inv = mk(0.f, 0.f, 0.f);
-            const float bestT = pb.z;
-            const int bestIdx = __float_as_int(pb.w);
-            V3 previous = mk(pc.x, pc.y, pc.z);
-            uint32_t slot = __float_as_uint(pc.w);
-            V3 throughput = mk(pd.x, pd.y, pd.z);
-            uint32_t k = __float_as_uint(pd.w);
-            int bounce = __float_as_int(pe.x);
-            uint32_t segments = __float_as_uint(pe.y);
-            const int iters = __float_as_int(pe.z);
-            V3 hitNormal = mk(0.0f, 0.0f, 0.0f);
-            bool emit = false;            // the ray continues: (ray.o, ray.d) hold the next segment
-            bool needPrimary = false;     // start frame k of pixel `slot`
-            bool needPixel = active && fresh;
-            if (active && !fresh) {
-                const bool hitAnything = bestIdx >= 0;
-                bool done = false;
-                V3 result = mk(0.0f, 0.0f, 0.0f);
-                FrameParams fp = {};
-                if (IDS) {
-                    ids[(size_t)slot * 3 + 0] = bestIdx; ids[(size_t)slot * 3 + 1] = (int32_t)__float_as_uint(bestT);
-                    ids[(size_t)slot * 3 + 2] = iters;
-                    needPixel = true;
-                } else if (BL < 2u) {
-                    if (SINGLE) fp = f0; else fp = frames[k];
-                    if (COUNT && hitAnything) tl.hits++;
-                    if (hitAnything) {
-                        const float4* T = reinterpret_cast<const float4*>(sp.tris + bestIdx);
-                        float4 a = T[0], b4 = T[1], c = T[2];
-                        V3 e1 = mk(a.w, b4.x, b4.y), e2 = mk(b4.z, b4.w, c.x);
-                        V3 nn = normalize3(cross3(e1, e2));
-                        hitNormal = (dot3(ray.d, nn) < 0.0f) ? nn : -nn;
-                    }
-                    if (BL == 0u) {
-                        const float itf = (float)iters;
-                        if (iters < 64) { float g = (1.0f / 64.0f) * itf; result = mk(g, g, g); }
-                        else if (iters < 128) { float kk = (float)(iters - 64); result = mk(1.0f - (0.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk, 1.0f - (1.0f / 64.0f) * kk); }
-                        else { float kk = (float)(iters - 128); result = mk(1.0f - (1.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk, 0.0f - (0.0f / 64.0f) * kk); }
-                    } else {
-                        result = abs3(hitNormal);
-                    }
-                    done = true;
-                } else {
-                    if (SINGLE) fp = f0; else fp = frames[k];
-                    if (COUNT && hitAnything) tl.hits++;
-                    const int i = bounce;
-                    uint32_t sx = Hashf(ray.o.x + ray.d.y) + Hash((uint32_t)i) + fp.hashX;
-                    uint32_t sy = Hashf(ray.o.y + ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
-                    float fsx = (float)sx, fsy = (float)sy;
-                    float seedx = div_by_uniform(fsx - nresx * floorf(div_by_uniform(fsx, nresx, rnresx)), nresx, rnresx);
-                    float seedy = div_by_uniform(fsy - nresy * floorf(div_by_uniform(fsy, nresy, rnresy)), nresy, rnresy);
-                    float ta_w = 0.0f, tc_x = 0.0f, tc_y = 0.0f;
-                    float4 tb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    Texels nA = {0u, 0u, 0u, 0u, 0, 0}, sk = {0u, 0u, 0u, 0u, 0, 0};
-                    if (hitAnything) {
-                        const TriRec* T = reinterpret_cast<const TriRec*>(reinterpret_cast<const char*>(sp.tris) + mul24((uint32_t)bestIdx, (uint32_t)sizeof(TriRec)));
-                        ta_w = T->e1x; tb = *reinterpret_cast<const float4*>(&T->e1y); tc_x = T->e2z; tc_y = __int_as_float(T->material);
-                        nA = fetch_noise(sp, seedx + 0.01534f, seedy + 0.183f);
-                    } else {
-                        sk = fetch_sky(sp, ray.d);
-                    }
-                    if (!hitAnything) {
-                        if (COUNT) tl.sky += (i == 0) ? 2u : 1u;
-                        result = throughput * resolve3(sk);
-                        done = true;
-                    } else {
-                        V3 e1 = mk(ta_w, tb.x, tb.y), e2 = mk(tb.z, tb.w, tc_x);
-                        V3 hitPoint = ray.o + (1.0f * bestT) * ray.d;
-                        V3 nn = normalize3(cross3(e1, e2));
-                        const bool frontFace = dot3(ray.d, nn) < 0.0f;
-                        hitNormal = frontFace ? nn : -nn;
-                        const MaterialRec m = lds_mat[__float_as_int(tc_y)];
-                        V3 hitColour = mk(m.colour[0], m.colour[1], m.colour[2]);
-                        if (m.isLight) {
-                            result = (throughput * hitColour) * m.transparency;
-                            done = true;
-                        } else {
-                            V3 next;
-                            int ii = i;
-                            if (COUNT) tl.noise++;
-                            float trRng = resolve(nA, 0);
-                            if (trRng < m.transparency) {
-                                float ri = frontFace ? m.airOverIndex : m.indexOverAir;
-                                float cos_theta = fminf(dot3(-ray.d, hitNormal), 1.0f);
-                                float sin_theta = sqrt_exact(1.0f - cos_theta * cos_theta);
-                                next = (ri * sin_theta <= 1.0f) ? refract3(ray.d, hitNormal, ri) : reflect3(ray.d, hitNormal);
-                                if (trRng < 0.5f) ii--;
-                            } else {
-                                if (COUNT) tl.noise += 2;
-                                const Texels nB = fetch_noise(sp, seedx - 0.062f, seedy - 0.0345f);
-                                const Texels nC = fetch_noise(sp, seedx, seedy);
-                                V3 n3 = resolve3(nB);
-                                V3 diffuseDir = normalize3(hitNormal + ((2.0f * n3) - mk(1.0f, 1.0f, 1.0f)) * m.roughness);
-                                V3 specularDir = reflect3(ray.d, hitNormal);
-                                bool isSpecular = resolve(nC, 1) < (1.0f - m.roughness);
-                                specularDir = mix3(specularDir, diffuseDir, m.roughness);
-                                next = isSpecular ? specularDir : diffuseDir;
-                                V3 spec = mk(m.specular[0], m.specular[1], m.specular[2]);
-                                throughput = throughput * (isSpecular ? mix3(spec, hitColour, m.metallic) : hitColour);
-                            }
-                            ray.o = hitPoint + 1e-4f * next;
-                            ray.d = next;
-                            V3 diff = abs3(throughput - previous);
-                            float distance = (diff.x + diff.y) + diff.z;
-                            int inc = (int)(BL / 4u);
-                            if (distance < 1.0f) ii += inc;
-                            if (distance < 0.4f) ii += inc;
-                            if (distance < 0.2f) ii += inc;
-                            ii++;
-                            bounce = ii;
-                            ++segments;
-                            if (!((uint32_t)ii <= BL) || segments >= kMaxSegments) { result = mk(0.0f, 0.0f, 0.0f); done = true; }
-                            else emit = true;
-                        }
-                    }
-                }
-                if (done) {
-                    V3 rgb = mk(0.0f, 0.0f, 0.0f) + result;
-                    rgb = rgb * (1.0f / 1.0f);
-                    previous = mix3(previous, rgb, fp.weight);
-                    if (COUNT) tl.paths++;
-                    if (tileCost) __hip_atomic_fetch_add(&tileCost[slot >> 6], segments + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ++k;
-                    if (k >= nFrames) {
-                        accum[slot] = make_float4(previous.x, previous.y, previous.z, 0.0f);
-                        needPixel = true;
-                    } else {
-                        needPrimary = true;
-                    }
-                }
-            }
-
-            // ---- ray slots whose pixel is finished take the next pixel of the group's tile ----
-            bool dies = false;
-            for (;;) {
-                const unsigned long long needMask = __ballot(needPixel);
-                if (needMask == 0ull) break;
-                const uint32_t want = (uint32_t)__popcll(needMask);
-                uint32_t gTile = 0, gStart = 0, gTake = 0, gEmpty = 0;
-                if (lane == 0) {
-                    for (;;) {
-                        const uint32_t w = lds_load(&ctrl[kPixelPool]), used = w & 127u;
-                        if (used == kPoolExhausted) { gEmpty = 1u; break; }
-                        if (used == kPoolRefilling) { __builtin_amdgcn_s_sleep(2); continue; }
-                        if (used < 64u) {
-                            const uint32_t take = min(want, 64u - used);
-                            if (atomicCAS(&ctrl[kPixelPool], w, w + take) == w) { gTile = w >> 7; gStart = used; gTake = take; break; }
-                            continue;
-                        }
-                        // the tile is used up: one wave fetches the next one from the launch's queues for the whole group
-                        if (atomicCAS(&ctrl[kPixelPool], w, (w & ~127u) | kPoolRefilling) != w) continue;
-                        uint32_t next = 0xffffffffu;
-                        while (bandsTried < 8u) {
-                            const uint32_t g = atomicAdd(&queueHeads[band], 1u);
-                            const uint32_t first = band * bandSize, last = min(first + bandSize, nGroups);
-                            if (first + g < last) { next = first + g; if (order) next = order[next]; break; }
-                            band = (band + 1u) % 8u;
-                            ++bandsTried;
-                        }
-                        lds_store(&ctrl[kPixelPool], next == 0xffffffffu ? kPoolExhausted : (next << 7));
-                    }
-                }
-                gEmpty = __builtin_amdgcn_readfirstlane(gEmpty);
-                if (gEmpty) { dies = needPixel; needPixel = false; break; }
-                gTile = __builtin_amdgcn_readfirstlane(gTile); gStart = __builtin_amdgcn_readfirstlane(gStart); gTake = __builtin_amdgcn_readfirstlane(gTake);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(needMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)needMask, 0u));
-                if (needPixel && rank < gTake) {
-                    const uint32_t inTile = gStart + rank;
-                    const uint32_t tile = gTile * sp.shardWorld + sp.shardRank;
-                    uint32_t tileX, tileY;
-                    divmod_uniform(tile, sp.tilesX, rTilesX, tileY, tileX);
-                    const uint32_t px = tileX * kTile + (inTile & 7u), py = tileY * kTile + (inTile >> 3);
-                    if (tile < nTiles && px < sp.width && py < sp.height) {      // (pixels of edge tiles outside the image: ask again)
-                        slot = gTile * 64u + inTile;
-                        k = 0;
-                        const float4 acc = IDS ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[slot];
-                        previous = mk(acc.x, acc.y, acc.z);
-                        needPixel = false;
-                        needPrimary = true;
-                    }
-                }
-            }
-            const unsigned long long deadMask = __ballot(dies);
-            if (deadMask != 0ull && lane == 0) atomicSub(&ctrl[kLive], (uint32_t)__popcll(deadMask));
-
-            // ---- primary rays: F:461-462 (pixel jitter precomputed per frame) ----
-            if (needPrimary) {
-                float jx, jy;
-                if (SINGLE) { jx = f0.jitterX; jy = f0.jitterY; } else { jx = frames[k].jitterX; jy = frames[k].jitterY; }
-                const uint32_t tile = (slot >> 6) * sp.shardWorld + sp.shardRank, inTile = slot & 63u;
-                uint32_t tileX, tileY;
-                divmod_uniform(tile, sp.tilesX, rTilesX, tileY, tileX);
-                const float fx = (float)(tileX * kTile + (inTile & 7u)) + 0.5f;
-                const float fy = (float)(tileY * kTile + (inTile >> 3)) + 0.5f;
-                if (COUNT) tl.noise++;
-                V3 pt = ((camPos + sp.vpD * facing) + (sp.vpW * (-0.5f + div_by_uniform((fx - 0.5f) + jx, resx, rresx))) * U) +
-                        (vpH * (-0.5f + div_by_uniform((fy - 0.5f) + jy, resy, rresy))) * Vd;
-                ray.o = camPos;
-                ray.d = normalize3(pt - camPos);
-                throughput = mk(1.0f, 1.0f, 1.0f);
-                bounce = 0; segments = 0;
-                emit = true;
-            }
-            if (emit) {
-                PoolRec* r = &pool[srid];
-                r->a = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
-                *reinterpret_cast<float2*>(&r->b.x) = make_float2(ray.d.y, ray.d.z);
-                r->c = make_float4(previous.x, previous.y, previous.z, __uint_as_float(slot));
-                r->d = make_float4(throughput.x, throughput.y, throughput.z, __uint_as_float(k));
-                *reinterpret_cast<uint2*>(&r->e.x) = make_uint2((uint32_t)bounce, segments);
-            }
-            pool_wait();                                          // the records are in L2 before their numbers are handed on
-            ring_push(traceRing, &ctrl[kTraceReserve], emit, srid + 1u, lane);
-            if (COUNT) rc.stop(3);
-        } else if (busy != 0) {
-            if (nInt >= nLeaf) {
-                int steps = 0;
-                bool descending = at_interior(L.cur);
-                do {
-                    if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += descending; }
-                    if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
-                    descending = at_interior(L.cur);
-                    ++steps;
-#if RT_DOUBLE_STEP
-                    if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += descending; }
-                    if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
-                    descending = at_interior(L.cur);
-                    ++steps;
-#endif
-                } while (steps < RT_INT_STEPS && __popcll(__ballot(descending)) * RT_KEEP_DEN >= nInt * RT_KEEP_NUM);
-                if (COUNT) rc.stop(1);
-            } else {
-                if (COUNT) { tl.rounds[2] += (lane == 0); tl.lanes[2] += at_leaf(L.cur); }
-                if (at_leaf(L.cur)) leaf_step<COUNT, ITERS>(sp, st, L, tl);
-                if (COUNT) rc.stop(2);
-            }
-        } else {
-            // nothing in this wave's lanes and nothing to fetch: the launch is over for the group once no ray is alive
-            if (lds_load(&ctrl[kLive]) == 0u) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-
-    uint32_t vals[kCounterSlots] = {tl.rays, tl.pops, tl.boxes, tl.tris, tl.noise, tl.sky, tl.paths, tl.hits,
-                                    tl.rounds[0], tl.rounds[1], tl.rounds[2], tl.rounds[3], tl.lanes[0], tl.lanes[1], tl.lanes[2], tl.lanes[3],
-                                    lane == 0 ? (uint32_t)(rc.cycles[0] >> 6) : 0u, lane == 0 ? (uint32_t)(rc.cycles[1] >> 6) : 0u,
-                                    lane == 0 ? (uint32_t)(rc.cycles[2] >> 6) : 0u, lane == 0 ? (uint32_t)(rc.cycles[3] >> 6) : 0u};
-    for (int s = 0; s < (int)kCounterSlots; ++s) {
-        if (!COUNT && s != (int)kRays) continue;
-        uint32_t v = vals[s];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) tally[(size_t)s * tallyStride + wave] += v;
-    }
-}
-
 // Sort keys for the tile hand-out order: band first (a contiguous eighth of the shard, so that neighbouring
 // tiles stay on one XCD), then descending cost. Clears the cost array for the next period.
 __global__ void order_keys_kernel(uint32_t* __restrict__ tileCost, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -1323,7 +833,6 @@ __global__ void untile_kernel(const float4* __restrict__ tiled, float4* __restri
 namespace rtd {
 
 uint32_t SpillEntriesPerWave() { return (uint32_t)(kMaxStack - kLdsStack) * 64u; }
-size_t PoolBytesPerGroup() { return sizeof(PoolRec) * kPoolRays; }
 
 // Number of waves that can be resident at once on the current device (the persistent grid size).
 uint32_t ResidentWaves() {
@@ -1340,45 +849,15 @@ void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* fra
                        single ? 1 : 0, queueHeads);
 }
 
-void LaunchTracePool(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
-                     void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
-                     const uint32_t* order, uint32_t* tileCost, void* poolArea);
-
-// poolArea != NULL selects the pooled scheduler (trace_pool_kernel), NULL the one-ray-per-lane scheduler (trace_kernel).
 void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
                  void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
-                 const uint32_t* order, uint32_t* tileCost, void* poolArea) {
-    if (poolArea) {
-        LaunchTracePool(count, ids, st, nWaves, sp, frames, nFrames, accum, tally, tallyStride, idsOut, spillArea, queueHeads, nGroups, order, tileCost, poolArea);
-        return;
-    }
+                 const uint32_t* order, uint32_t* tileCost) {
     float4* a = static_cast<float4*>(accum);
     uint2* sa = static_cast<uint2*>(spillArea);
     dim3 grid((nWaves + (uint32_t)kWgWaves - 1u) / (uint32_t)kWgWaves), block(64 * kWgWaves);     // the per-wave arrays hold a multiple of kWgWaves
     const bool single = nFrames == 1u;
     const bool heat = sp.bounceLimit == 0u;        // the only view that shows iterationsCount
 #define RT_LAUNCH(C, I, S, T) hipLaunchKernelGGL((trace_kernel<C, I, S, T>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost)
-    if (ids) RT_LAUNCH(true, true, true, true);
-    else if (count && single) RT_LAUNCH(true, false, true, true);
-    else if (count) RT_LAUNCH(true, false, false, true);
-    else if (single && heat) RT_LAUNCH(false, false, true, true);
-    else if (single) RT_LAUNCH(false, false, true, false);
-    else if (heat) RT_LAUNCH(false, false, false, true);
-    else RT_LAUNCH(false, false, false, false);
-#undef RT_LAUNCH
-}
-
-// The pooled scheduler always runs whole work-groups: the grid is the machine's resident groups (fewer for tiny shards).
-void LaunchTracePool(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
-                     void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
-                     const uint32_t* order, uint32_t* tileCost, void* poolArea) {
-    float4* a = static_cast<float4*>(accum);
-    uint2* sa = static_cast<uint2*>(spillArea);
-    PoolRec* pa = static_cast<PoolRec*>(poolArea);
-    dim3 grid((nWaves + (uint32_t)kWgWaves - 1u) / (uint32_t)kWgWaves), block(64 * kWgWaves);
-    const bool single = nFrames == 1u;
-    const bool heat = sp.bounceLimit == 0u;
-#define RT_LAUNCH(C, I, S, T) hipLaunchKernelGGL((trace_pool_kernel<C, I, S, T>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost, pa)
     if (ids) RT_LAUNCH(true, true, true, true);
     else if (count && single) RT_LAUNCH(true, false, true, true);
     else if (count) RT_LAUNCH(true, false, false, true);
