@@ -186,6 +186,26 @@ int rt_shard_export(rt_context *ctx, void *dstDevice);
  * rank order (what a gather collective delivers). Scatters them into this context's image. */
 int rt_accum_assemble(rt_context *ctx, const void *gatheredDevice, uint32_t world);
 
+/* ---- several GPUs in one process: the tile shards of one image, gathered over RCCL (no counterpart in the reference) ----
+ * rt_group_create makes one sharded context per listed device (rank r renders tiles t % n == r on devices[r]), an
+ * unsharded root context on devices[0] that receives the assembled image, and an RCCL communicator over the devices
+ * (RCCL is loaded at run time; a process that never creates a group does not need it). Scene, materials, textures,
+ * camera and bounce limit are uploaded per rank through rt_group_rank(g, r) with the calls above (every rank holds the
+ * whole scene). rt_group_render queues the frames on every rank. rt_group_gather sends every rank's shard to rank 0
+ * (ncclSend / ncclRecv in one group call: each peer pushes over its own xGMI link) and scatters them into the root
+ * context's image, all queued on the devices' streams; read the image with rt_accum_read / rt_postprocess on
+ * rt_group_root(g). The assembled image equals an unsharded render of the same frames bit for bit. */
+typedef struct rt_group rt_group;
+int rt_group_create(const int *devices, uint32_t nDevices, uint32_t width, uint32_t height, rt_group **out);
+void rt_group_destroy(rt_group *group);
+uint32_t rt_group_size(const rt_group *group);
+rt_context *rt_group_rank(rt_group *group, uint32_t rank);
+rt_context *rt_group_root(rt_group *group);
+int rt_group_render(rt_group *group, uint32_t firstFrameIndex, uint32_t nFrames, const float *seeds3);
+int rt_group_gather(rt_group *group);
+int rt_group_sync(rt_group *group);
+const char *rt_group_last_error(const rt_group *group);
+
 /* Queue this context's work on a caller-provided hipStream_t (NULL = the context's own). */
 int rt_set_stream(rt_context *ctx, void *hipStream);
 

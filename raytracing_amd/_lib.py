@@ -74,6 +74,15 @@ SIGNATURES = {
     "rt_shard_device_ptr": (I, [P, ctypes.POINTER(P)]),
     "rt_shard_export": (I, [P, P]),
     "rt_accum_assemble": (I, [P, P, U32]),
+    "rt_group_create": (I, [ctypes.POINTER(ctypes.c_int), U32, U32, U32, ctypes.POINTER(P)]),
+    "rt_group_destroy": (None, [P]),
+    "rt_group_size": (U32, [P]),
+    "rt_group_rank": (P, [P, U32]),
+    "rt_group_root": (P, [P]),
+    "rt_group_render": (I, [P, U32, U32, P]),
+    "rt_group_gather": (I, [P]),
+    "rt_group_sync": (I, [P]),
+    "rt_group_last_error": (ctypes.c_char_p, [P]),
     "rt_set_stream": (I, [P, P]),
     "rt_kernel_time": (I, [P, ctypes.POINTER(ctypes.c_double), U64P, I]),
     "rth_scene_load": (I, [ctypes.POINTER(ctypes.c_char_p), U32, I, ctypes.POINTER(P)]),

@@ -737,3 +737,172 @@ int rt_set_counting(rt_context* c, int on) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// rt_group: one image rendered by several GPUs of this process (tile sharding), shards gathered over RCCL.
+// RCCL is looked up at run time (dlopen) so that the library has no load-time dependency on it: programs that use
+// one GPU never touch it, and in a process that already has an RCCL loaded (PyTorch brings its own) that one serves.
+// ---------------------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl& LoadRccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) return x;
+        x.CommInitAll = (decltype(x.CommInitAll))dlsym(x.lib, "ncclCommInitAll");
+        x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.lib, "ncclCommDestroy");
+        x.GroupStart = (decltype(x.GroupStart))dlsym(x.lib, "ncclGroupStart");
+        x.GroupEnd = (decltype(x.GroupEnd))dlsym(x.lib, "ncclGroupEnd");
+        x.Send = (decltype(x.Send))dlsym(x.lib, "ncclSend");
+        x.Recv = (decltype(x.Recv))dlsym(x.lib, "ncclRecv");
+        x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.lib, "ncclGetErrorString");
+        x.ok = x.CommInitAll && x.CommDestroy && x.GroupStart && x.GroupEnd && x.Send && x.Recv && x.GetErrorString;
+        return x;
+    }();
+    return r;
+}
+
+}  // namespace
+
+struct rt_group {
+    std::vector<int> devices;
+    std::vector<rt_context*> ranks;      // sharded contexts, rank r on devices[r]
+    rt_context* root = nullptr;          // unsharded context on devices[0]: receives the assembled image
+    std::vector<ncclComm_t> comms;
+    void* dGathered = nullptr;           // on devices[0]: world shards back to back
+    hipEvent_t gathered = nullptr;       // recorded on rank 0's stream behind the receives
+    size_t shardFloats = 0;
+    std::string error;
+};
+
+namespace {
+int GroupFail(rt_group* g, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (g) g->error = buf;
+    g_globalError = buf;
+    return code;
+}
+}  // namespace
+
+extern "C" {
+
+const char* rt_group_last_error(const rt_group* g) { return g ? g->error.c_str() : g_globalError.c_str(); }
+
+void rt_group_destroy(rt_group* g) {
+    if (!g) return;
+    Rccl& nc = LoadRccl();
+    for (size_t r = 0; r < g->ranks.size(); ++r) if (g->ranks[r]) (void)rt_sync(g->ranks[r]);
+    if (g->root) (void)rt_sync(g->root);
+    for (size_t r = 0; r < g->comms.size(); ++r)
+        if (g->comms[r] && nc.ok) { (void)hipSetDevice(g->devices[r]); (void)nc.CommDestroy(g->comms[r]); }
+    if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+    if (g->gathered) (void)hipEventDestroy(g->gathered);
+    if (g->dGathered) (void)hipFree(g->dGathered);
+    for (rt_context* c : g->ranks) rt_destroy(c);
+    rt_destroy(g->root);
+    delete g;
+}
+
+int rt_group_create(const int* devices, uint32_t nDevices, uint32_t width, uint32_t height, rt_group** out) try {
+    if (!out) return GroupFail(nullptr, RT_ERR_INVALID, "rt_group_create: out is NULL");
+    *out = nullptr;
+    if (!devices || nDevices == 0 || nDevices > 64) return GroupFail(nullptr, RT_ERR_INVALID, "rt_group_create: need 1..64 devices");
+    for (uint32_t a = 0; a < nDevices; ++a)
+        for (uint32_t b = a + 1; b < nDevices; ++b)
+            if (devices[a] == devices[b]) return GroupFail(nullptr, RT_ERR_INVALID, "rt_group_create: device %d listed twice (one rank per GPU)", devices[a]);
+    Rccl& nc = LoadRccl();
+    if (!nc.ok) return GroupFail(nullptr, RT_ERR_DEVICE, "rt_group_create: RCCL (librccl.so.1) could not be loaded");
+    rt_group* g = new rt_group();
+    g->devices.assign(devices, devices + nDevices);
+    auto fail = [&](int rc, const char* what) { std::string msg = std::string(what) + ": " + rt_last_global_error(); rt_group_destroy(g); return GroupFail(nullptr, rc, "%s", msg.c_str()); };
+    for (uint32_t r = 0; r < nDevices; ++r) {
+        rt_context* c = nullptr;
+        int rc = rt_create(devices[r], width, height, &c);
+        if (rc != RT_OK) return fail(rc, "rt_group_create: rank context");
+        g->ranks.push_back(c);
+        rc = rt_set_shard(c, r, nDevices);
+        if (rc != RT_OK) { g_globalError = c->error; return fail(rc, "rt_group_create: rt_set_shard"); }
+    }
+    int rc = rt_create(devices[0], width, height, &g->root);
+    if (rc != RT_OK) return fail(rc, "rt_group_create: root context");
+    g->shardFloats = (size_t)g->ranks[0]->sp.shardTiles * 64 * 4;
+    if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&g->dGathered, g->shardFloats * sizeof(float) * nDevices) != hipSuccess ||
+        hipEventCreateWithFlags(&g->gathered, hipEventDisableTiming) != hipSuccess) {
+        g_globalError = "device memory for the gathered shards";
+        return fail(RT_ERR_DEVICE, "rt_group_create");
+    }
+    g->comms.assign(nDevices, nullptr);
+    ncclResult_t nr = nc.CommInitAll(g->comms.data(), (int)nDevices, devices);
+    if (nr != ncclSuccess) { g_globalError = nc.GetErrorString(nr); return fail(RT_ERR_DEVICE, "rt_group_create: ncclCommInitAll"); }
+    *out = g;
+    return RT_OK;
+} catch (const std::exception& e) {
+    return GroupFail(nullptr, RT_ERR_DEVICE, "rt_group_create: %s", e.what());
+}
+
+uint32_t rt_group_size(const rt_group* g) { return g ? (uint32_t)g->ranks.size() : 0u; }
+rt_context* rt_group_rank(rt_group* g, uint32_t rank) { return (g && rank < g->ranks.size()) ? g->ranks[rank] : nullptr; }
+rt_context* rt_group_root(rt_group* g) { return g ? g->root : nullptr; }
+
+int rt_group_render(rt_group* g, uint32_t firstFrameIndex, uint32_t nFrames, const float* seeds3) {
+    if (!g) return RT_ERR_INVALID;
+    for (rt_context* c : g->ranks) {
+        int rc = rt_render(c, firstFrameIndex, nFrames, seeds3);
+        if (rc != RT_OK) return GroupFail(g, rc, "rt_group_render: %s", rt_last_error(c));
+    }
+    return RT_OK;
+}
+
+int rt_group_gather(rt_group* g) {
+    if (!g) return RT_ERR_INVALID;
+    Rccl& nc = LoadRccl();
+    const uint32_t world = (uint32_t)g->ranks.size();
+    // One group call: every rank sends its shard (behind its frames, on its own stream) to rank 0, which receives them
+    // back to back. Every peer has its own xGMI link to rank 0, so the sends run side by side.
+    ncclResult_t nr = nc.GroupStart();
+    for (uint32_t r = 0; r < world && nr == ncclSuccess; ++r)
+        nr = nc.Send(g->ranks[r]->dAccum, g->shardFloats, ncclFloat, 0, g->comms[r], g->ranks[r]->stream);
+    for (uint32_t r = 0; r < world && nr == ncclSuccess; ++r)
+        nr = nc.Recv(static_cast<float*>(g->dGathered) + (size_t)r * g->shardFloats, g->shardFloats, ncclFloat, (int)r, g->comms[0], g->ranks[0]->stream);
+    ncclResult_t ne = nc.GroupEnd();
+    if (nr == ncclSuccess) nr = ne;
+    if (nr != ncclSuccess) return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: RCCL: %s", nc.GetErrorString(nr));
+    // the root context assembles on its own stream once the receives are done
+    HIP_TRY(g->root, hipSetDevice(g->devices[0]));
+    if (hipEventRecord(g->gathered, g->ranks[0]->stream) != hipSuccess || hipStreamWaitEvent(g->root->stream, g->gathered, 0) != hipSuccess)
+        return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: ordering the assembly behind the receives failed");
+    int rc = rt_accum_assemble(g->root, g->dGathered, world);
+    if (rc != RT_OK) return GroupFail(g, rc, "rt_group_gather: %s", rt_last_error(g->root));
+    return RT_OK;
+}
+
+int rt_group_sync(rt_group* g) {
+    if (!g) return RT_ERR_INVALID;
+    for (rt_context* c : g->ranks) { int rc = rt_sync(c); if (rc != RT_OK) return GroupFail(g, rc, "rt_group_sync: %s", rt_last_error(c)); }
+    int rc = rt_sync(g->root);
+    if (rc != RT_OK) return GroupFail(g, rc, "rt_group_sync: %s", rt_last_error(g->root));
+    return RT_OK;
+}
+
+}  // extern "C"
+

@@ -101,9 +101,13 @@ def build_scene(tri9, mat_slot, materials_rows=None, build_threads=1, max_leaf=0
 class Renderer:
     """One GPU path-tracing context (rt_context)."""
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, _borrowed=None):
         self.L = _lib.lib()
         self.W, self.H = width, height
+        self._owned = _borrowed is None
+        if _borrowed is not None:          # a context that belongs to a Group
+            self.h = ctypes.c_void_p(_borrowed)
+            return
         h = ctypes.c_void_p()
         rc = self.L.rt_create(device, width, height, ctypes.byref(h))
         if rc != 0:
@@ -112,7 +116,8 @@ class Renderer:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.rt_destroy(self.h)
+            if self._owned:
+                self.L.rt_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -230,3 +235,43 @@ class Renderer:
 
     def set_stream(self, hip_stream):
         self._ck(self.L.rt_set_stream(self.h, ctypes.c_void_p(hip_stream)), "rt_set_stream")
+
+
+class Group:
+    """Several GPUs of this process rendering one image (rt_group): `ranks` are the sharded per-device renderers (upload
+    scene, textures, camera to each), `root` is the unsharded renderer that holds the image after gather()."""
+
+    def __init__(self, devices, width, height):
+        self.L = _lib.lib()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        rc = self.L.rt_group_create(arr, len(devices), width, height, ctypes.byref(h))
+        if rc != 0:
+            raise RtError("rt_group_create: " + self.L.rt_group_last_error(None).decode())
+        self.h = h
+        self.ranks = [Renderer(width, height, _borrowed=self.L.rt_group_rank(h, r)) for r in range(self.L.rt_group_size(h))]
+        self.root = Renderer(width, height, _borrowed=self.L.rt_group_root(h))
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RtError("%s failed (%d): %s" % (what, rc, self.L.rt_group_last_error(self.h).decode()))
+
+    def render(self, first_frame, seeds3):
+        s = np.ascontiguousarray(seeds3, dtype=np.float32).reshape(-1, 3)
+        self._ck(self.L.rt_group_render(self.h, int(first_frame), len(s), s.ctypes.data), "rt_group_render")
+
+    def gather(self):
+        self._ck(self.L.rt_group_gather(self.h), "rt_group_gather")
+
+    def sync(self):
+        self._ck(self.L.rt_group_sync(self.h), "rt_group_sync")
+
+    def close(self):
+        if getattr(self, "h", None):
+            for r in self.ranks + [self.root]:
+                r.close()
+            self.L.rt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

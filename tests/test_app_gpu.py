@@ -121,3 +121,25 @@ def test_headless_executable_matches_python_driver(objects, tmp_path):
     _, want = app.read_display()
     assert (got == want).all()
     app.close(); rr.close()
+
+
+def test_headless_executable_on_a_device_group_writes_the_same_image(objects, tmp_path):
+    """--gpus 1: the C++ host on top of rt_group (sharded rank, RCCL gather to the root context, bloom chain there)
+    against the same frames on a plain context. With the scene cache on, so the second run loads the blob."""
+    import subprocess
+    from PIL import Image
+    root = tmp_path / "install"
+    (root / "Sky").mkdir(parents=True)
+    for f, name in enumerate(("right", "left", "top", "bottom", "front", "back")):
+        Image.fromarray(SKY[f], "RGBA").save(str(root / "Sky" / (name + ".png")))
+    Image.fromarray(NOISE, "RGB").save(str(root / "noise.png"))
+    scenes.write_ini(str(root / "RayTracer.ini"), os.path.dirname(objects[0]), [os.path.basename(p) for p in objects], skybox_path=str(root / "Sky"))
+    exe = os.path.join(os.path.dirname(ra.__file__), "raytracer_headless")
+    common = [exe, "--ini", str(root / "RayTracer.ini"), "--noise", str(root / "noise.png"), "--width", str(W), "--height", str(H),
+              "--frames", "6", "--cache", str(tmp_path / "cache")]
+    one = subprocess.run(common + ["--out", str(tmp_path / "one")], capture_output=True, text=True, timeout=120)
+    assert one.returncode == 0, one.stdout + one.stderr
+    grp = subprocess.run(common + ["--gpus", "1", "--out", str(tmp_path / "grp")], capture_output=True, text=True, timeout=120)
+    assert grp.returncode == 0, grp.stdout + grp.stderr
+    assert "on 1 GPUs" in grp.stdout and len(os.listdir(str(tmp_path / "cache"))) == 1
+    assert (np.asarray(Image.open(str(tmp_path / "one.png"))) == np.asarray(Image.open(str(tmp_path / "grp.png")))).all()

@@ -122,3 +122,37 @@ def test_gpu_sharded_render_equals_unsharded(world):
     assert total_rays == whole.counters()["rays"]
     root.close()
     whole.close()
+
+
+@pytest.mark.gpu
+def test_group_of_one_device_gathers_over_rccl_and_equals_unsharded():
+    """rt_group on the one GPU a test box has: the whole path (sharded context, ncclSend/ncclRecv in one group call,
+    assembly on the root context) with world size 1, against a plain unsharded render; gather twice, as a progressive
+    viewer would."""
+    import raytracing_amd as ra
+    from raytracing_amd import scenes
+    from util import differing_pixels, make_scene, setup
+    W, H = 200, 120
+    sc = make_scene("sponza_like", target_tris=6000)
+    noise, sky, seeds = scenes.noise_texture(64, 48), scenes.sky_cubemap(32), scenes.frame_seeds(5)
+    g = ra.Group([0], W, H)
+    assert len(g.ranks) == 1
+    for r in g.ranks:
+        setup(r, sc, noise, sky, bounce_limit=4)
+    whole = ra.Renderer(W, H)
+    setup(whole, sc, noise, sky, bounce_limit=4)
+    g.render(0, seeds[:3])
+    g.gather()
+    whole.render(0, seeds[:3])
+    assert differing_pixels(g.root.read_accum(), whole.read_accum()) == 0
+    g.render(3, seeds[3:])
+    g.gather()
+    g.sync()
+    whole.render(3, seeds[3:])
+    assert differing_pixels(g.root.read_accum(), whole.read_accum()) == 0
+    rgba, rgb8 = g.root.postprocess(True)              # the root context is an ordinary one: bloom chain on the gathered image
+    want_rgba, want_rgb8 = whole.postprocess(True)
+    assert (rgb8 == want_rgb8).all()
+    with pytest.raises(ra.RtError):
+        ra.Group([0, 0], W, H)                          # one rank per GPU
+    g.close(); whole.close()
