@@ -27,6 +27,7 @@ uint32_t ResidentWaves();
 void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigned long long* out, int slots);
 void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t width, uint32_t height, uint32_t tilesX, uint32_t world,
                   uint32_t shardTiles, bool toTiled);
+void LaunchRetile(hipStream_t st, const void* gathered, void* tiled, uint32_t nTiles, uint32_t world, uint32_t shardTiles);
 int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint32_t width, uint32_t height, int bloomOn, void** scratch,
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
@@ -705,8 +706,7 @@ int rt_accum_assemble(rt_context* c, const void* gatheredDevice, uint32_t world)
     if (!c->dAccum) return Fail(c, RT_ERR_STATE, "rt_accum_assemble: no accumulation buffer (rt_set_shard failed earlier)");
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t nTiles = c->sp.tilesX * c->sp.tilesY, per = (nTiles + world - 1) / world;
-    LaunchUntile(c->stream, gatheredDevice, c->dLinear, c->width, c->height, c->sp.tilesX, world, per, false);
-    LaunchUntile(c->stream, c->dAccum, c->dLinear, c->width, c->height, c->sp.tilesX, 1, c->sp.shardTiles, true);
+    LaunchRetile(c->stream, gatheredDevice, c->dAccum, nTiles, world, per);      // one pass: tiles move as 1 KiB blocks
     HIP_TRY(c, hipGetLastError());
     return RT_OK;
 }

@@ -826,6 +826,15 @@ __global__ void untile_kernel(const float4* __restrict__ tiled, float4* __restri
     else linear[(size_t)y * width + x] = tiled[slot];
 }
 
+// Gathered shards (rank-major: shard r holds tiles r, r + world, ...) -> the tile-major image of an unsharded context:
+// whole 1 KiB tiles change place, nothing inside a tile moves.
+__global__ void retile_kernel(const float4* __restrict__ gathered, float4* __restrict__ tiled, uint32_t nTiles, uint32_t world, uint32_t shardTiles) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tile = i >> 6, lane = i & 63u;
+    if (tile >= nTiles) return;
+    tiled[i] = gathered[((size_t)(tile % world) * shardTiles + tile / world) * 64u + lane];
+}
+
 }  // namespace
 
 
@@ -882,6 +891,11 @@ void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t widt
     dim3 block(32, 8), grid((width + 31) / 32, (height + 7) / 8);
     hipLaunchKernelGGL(untile_kernel, grid, block, 0, st, static_cast<const float4*>(tiled), static_cast<float4*>(linear), width, height,
                        tilesX, world, shardTiles, toTiled ? 1 : 0);
+}
+
+void LaunchRetile(hipStream_t st, const void* gathered, void* tiled, uint32_t nTiles, uint32_t world, uint32_t shardTiles) {
+    hipLaunchKernelGGL(retile_kernel, dim3((nTiles * 64u + 255u) / 256u), dim3(256), 0, st, static_cast<const float4*>(gathered), static_cast<float4*>(tiled),
+                       nTiles, world, shardTiles);
 }
 
 }  // namespace rtd

@@ -9,7 +9,7 @@ from raytracing_amd import scenes
 name = sys.argv[1] if len(sys.argv) > 1 else "sponza_like_3840x2160_b8"
 sc, W, H, bl = bench.load_workload(name, 16)
 seeds = scenes.frame_seeds(12)
-for world in (1, 2, 4, 8):
+for world in (1, 2, 4, 8, 32, 128, 1024, 16384):
     r = ra.Renderer(W, H)
     bench.setup(r, sc, scenes.noise_texture(), scenes.sky_cubemap(), bl)
     r.set_shard(0, world)
