@@ -134,6 +134,13 @@ int rt_sync(rt_context *ctx);
  * output (it emits colours only); it exposes the values Fragment.glsl:265-326 computes. */
 int rt_primary_ids(rt_context *ctx, const float *seed3, int32_t *out3);
 
+/* Parity channel: the tracer's ray/triangle test, hitTriangle (Fragment.glsl:207-240), on n independent pairs of one
+ * triangle (tri12: three corners, xyz0 each, as in rt_scene_upload) and one ray (origin and direction, 3 floats each;
+ * the direction is used as given). hitOut[i] = 1 and tOut[i] = the distance when ray i hits triangle i, else 0 and 0.
+ * Runs the device function the render uses, on the triangle record the upload makes; needs no scene. Host arrays. */
+int rt_probe_triangles(rt_context *ctx, uint32_t n, const float *tri12, const float *origins3, const float *directions3,
+                       uint8_t *hitOut, float *tOut);
+
 /* Bloom chain + final composite of one frame (src/main.cpp:242-275 with
  * extractBrightFragment.glsl, bloomFragment.glsl, finalFragment.glsl); bloom_on == 0 is the
  * raw blit of src/main.cpp:235-240. Either output may be NULL. rgb8_out is what

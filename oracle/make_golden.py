@@ -15,6 +15,9 @@ What is recorded (inputs AND the reference's outputs, as data):
                  generation time and compiled into a probe shader; it is not stored): directions in, colours out.
                  Half of the directions are picked because two algebraically equal forms of the rotation's x component
                  round differently for them, which moves the looked-up colour by one 8-bit code
+  triangle_edges.npz  the reference's own hitTriangle (cut out of Fragment.glsl when this script runs) on llvmpipe, on
+                 (triangle, ray) pairs whose ray is aimed at a point on one of the triangle's edges: there the last
+                 bit of u, v and u + v decides, and llvmpipe does not evaluate u + v as the source writes it
   bvh_*.npz      triangles in, (nodes, reordered triangles, material ids) out of the reference's
                  own BvhTree (compiled from its sources into oracle/_ref/libref_host.so)
   loader_*.npz   object files written by us in the reference's formats (tests/golden/objects/), and
@@ -192,6 +195,102 @@ def sky_rotation_fixture(gl):
     print("sky_rotation: %d directions" % len(dirs))
 
 
+def triangle_edge_fixture(gl):
+    """The reference's own hitTriangle (cut out of its fragment shader at generation time) on llvmpipe, for rays aimed at
+    the edges of their triangle: on an edge the barycentric tests u >= 0, v >= 0 and u + v <= 1 are decided by the last
+    bit, so these cases pin how llvmpipe evaluates them (u + v in particular is not evaluated as written)."""
+    import re
+    from probe_tex import prog
+    from rt_oracle import hit_triangles
+    text = open(os.path.join(os.environ.get("RT_REFERENCE_DIR", "/root/reference"), "src", "shaders", "Fragment.glsl")).read()
+
+    def cut(pattern):
+        return re.search(pattern, text, re.S).group(0)
+    parts = [cut(r"struct Material\s*\{.*?\};"), cut(r"struct Triangle\s*\{.*?\};"), cut(r"struct Ray\s*\{.*?\};"),
+             cut(r"struct HitRecord\s*\{.*?\};"), cut(r"void SetFaceNormal\(.*?\n}"), cut(r"vec3 RayAt\(.*?\n}"),
+             cut(r"Ray MakeRay\(.*?\n}"), cut(r"bool hitTriangle\(.*?\n}")]
+    p = prog(gl, "#version 430 core\nout vec4 color;\nuniform sampler2D P0;\nuniform sampler2D P1;\nuniform sampler2D P2;\n"
+             "uniform sampler2D O;\nuniform sampler2D D;\n" + "\n".join(parts) +
+             "void main(){ ivec2 p = ivec2(gl_FragCoord.xy);\nTriangle tri;\ntri.position = texelFetch(P0, p, 0).xyz;\n"
+             "tri.position2 = texelFetch(P1, p, 0).xyz;\ntri.position3 = texelFetch(P2, p, 0).xyz;\n"
+             "Ray r = MakeRay(texelFetch(O, p, 0).xyz, texelFetch(D, p, 0).xyz, 1.0);\nHitRecord rec;\nrec.t = 1.0 / 0.0;\n"
+             "bool hit = hitTriangle(tri, r, rec);\ncolor = vec4(hit ? 1.0 : 0.0, hit ? rec.t : 0.0, 0.0, 1.0); }\n")
+    W = H = 1024
+    n = W * H
+    rng = np.random.default_rng(41)
+    t_out = gl.tex_f32(0, W, H)
+    fb = gl.fbo(t_out)
+    keep = {k: [] for k in ("tri12", "origins", "directions", "hit", "t")}
+    n_hit_differs_when_as_written = 0
+    for rnd in range(4):
+        v0 = rng.uniform(-8, 8, (n, 3)).astype(f32)
+        e1 = rng.uniform(-12, 12, (n, 3)).astype(f32)
+        e2 = rng.uniform(-12, 12, (n, 3)).astype(f32)
+        # half of the triangles are halves of axis-aligned rectangles on a half-unit grid, like walls and floors
+        grid = rng.random(n) < 0.5
+        v0[grid] = np.round(v0[grid] * 2) / 2
+        axis = rng.integers(0, 3, n)
+        a, b = (np.round(rng.uniform(1, 24, n)) / 2).astype(f32), (np.round(rng.uniform(1, 24, n)) / 2).astype(f32)
+        sign = rng.choice(np.array([-1, 1], f32), (n, 2))
+        for k in range(3):
+            m = grid & (axis == k)
+            e1[m] = 0
+            e2[m] = 0
+            e1[m, (k + 1) % 3] = a[m] * sign[m, 0]
+            e2[m, (k + 2) % 3] = b[m] * sign[m, 1]
+        v1, v2 = (v0 + e1).astype(f32), (v0 + e2).astype(f32)
+        # a point on one of the three edges (mostly the one opposite the first corner, where u + v = 1)
+        which = rng.choice(3, n, p=[0.6, 0.2, 0.2])
+        s = rng.random(n).astype(f32)[:, None]
+        pa = np.where((which == 0)[:, None], v1, v0)
+        pb = np.where((which == 1)[:, None], v1, v2)
+        target = (pa + s * (pb - pa)).astype(f32)
+        origin = rng.uniform(-6, 6, (n, 3)).astype(f32)
+        dirn = (target - origin).astype(np.float64)
+        dirn = (dirn / np.sqrt((dirn ** 2).sum(-1, keepdims=True))).astype(f32)
+
+        def rgba(x):
+            out = np.zeros((H, W, 4), f32)
+            out[..., :3] = x.reshape(H, W, 3)
+            return out
+        for unit, (name, arr) in enumerate((("P0", v0), ("P1", v1), ("P2", v2), ("O", origin), ("D", dirn)), start=3):
+            gl.tex_f32(unit, W, H, rgba(arr), linear=False)
+            gl.u1i(p, name, unit)
+        gl.draw(p, fb, W, H)
+        gl.finish()
+        got = gl.read_f32(0, t_out, W, H).reshape(-1, 4)
+        tri12 = np.zeros((n, 12), f32)
+        tri12[:, 0:3], tri12[:, 4:7], tri12[:, 8:11] = v0, v1, v2
+        hit, t = hit_triangles(tri12, origin, dirn)
+        bad = np.nonzero((hit != (got[:, 0] > 0.5)) | (t.view(np.uint32) != got[:, 1].view(np.uint32)))[0]
+        if len(bad):
+            i = bad[0]
+            raise SystemExit("the CPU restatement's hitTriangle differs from llvmpipe in %d of %d cases, e.g. triangle %r origin %r direction %r"
+                             % (len(bad), n, tri12[i].tolist(), origin[i].tolist(), dirn[i].tolist()))
+        # the cases worth keeping: those within a few ulp of an edge (float64 barycentrics), plus a random sample
+        E1, E2, Dd, S = e1.astype(np.float64), e2.astype(np.float64), dirn.astype(np.float64), (origin - v0).astype(np.float64)
+        Hh = np.cross(Dd, E2)
+        det = (E1 * Hh).sum(-1)
+        u = (S * Hh).sum(-1) / det
+        v = (Dd * np.cross(S, E1)).sum(-1) / det
+        near = np.nonzero((np.abs(u + v - 1) < 2e-7) | (np.abs(u) < 1e-7) | (np.abs(v) < 1e-7))[0]
+        # as written: u + v with both products rounded first
+        idet = (f32(1) / det.astype(f32)).astype(f32)
+        as_written = ((idet * (S * Hh).sum(-1).astype(f32)).astype(f32) + (idet * (Dd * np.cross(S, E1)).sum(-1).astype(f32)).astype(f32)).astype(f32)
+        factored = (idet * ((S * Hh).sum(-1).astype(f32) + (Dd * np.cross(S, E1)).sum(-1).astype(f32)).astype(f32)).astype(f32)
+        n_hit_differs_when_as_written += int(((as_written > 1) != (factored > 1)).sum())
+        pick = np.concatenate([rng.choice(near, min(len(near), 1536), replace=False), rng.integers(0, n, 512)])
+        keep["tri12"].append(tri12[pick])
+        keep["origins"].append(origin[pick])
+        keep["directions"].append(dirn[pick])
+        keep["hit"].append((got[pick, 0] > 0.5))
+        keep["t"].append(got[pick, 1].copy())
+    out = {k: np.concatenate(v) for k, v in keep.items()}
+    np.savez_compressed(os.path.join(GOLD, "triangle_edges.npz"), manifest=manifest(gl), **out)
+    print("triangle_edges: %d cases kept (%d hits); about %d of the %d probed change sides if u + v is evaluated as written"
+          % (len(out["hit"]), int(out["hit"].sum()), n_hit_differs_when_as_written, 4 * n))
+
+
 class RefHost:
     def __init__(self):
         L = ctypes.CDLL(os.path.join(HERE, "_ref", "libref_host.so"))
@@ -344,6 +443,9 @@ def main():
     if "--only-sky-rotation" in sys.argv:
         sky_rotation_fixture(gl)
         return
+    if "--only-triangle-edges" in sys.argv:
+        triangle_edge_fixture(gl)
+        return
     noise = scenes.noise_texture(64, 48, seed=7)
     sky = scenes.sky_cubemap(32, seed=3)
     cam2 = dict(position=(1.5, -2.0, 0.7), facing=tuple(float(x) for x in (np.array([0.8, 0.55, -0.2], f32) / np.linalg.norm(np.array([0.8, 0.55, -0.2], f32)))),
@@ -361,6 +463,7 @@ def main():
                    [(8, 8)])
     texture_fixture(gl)
     sky_rotation_fixture(gl)
+    triangle_edge_fixture(gl)
     post_fixture(gl)
     ref = RefHost()
     bvh_fixtures(ref)

@@ -38,6 +38,7 @@ def _load():
     L.orc_sample_noise.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_void_p]
     L.orc_sample_sky.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.orc_sample_sky_rotated.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_hit_triangles.argtypes = [ctypes.c_uint32] + [ctypes.c_void_p] * 5
     return L
 
 
@@ -129,6 +130,19 @@ class Oracle:
         out = np.zeros(3, dtype=np.float32)
         self.L.orc_sample_sky_rotated(self.h, d.ctypes.data, out.ctypes.data)
         return out
+
+
+def hit_triangles(tri12, origins, directions):
+    """hitTriangle of the tracer on n independent (triangle, ray) pairs: tri12 (n,12) as in the triangle buffer,
+    origins and directions (n,3). Returns (hit (n,) bool, t (n,) float32, 0 where missed)."""
+    L = _load()
+    tri12 = np.ascontiguousarray(tri12, dtype=np.float32).reshape(-1, 12)
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    assert len(o) == len(tri12) == len(d)
+    hit, t = np.zeros(len(o), dtype=np.uint8), np.zeros(len(o), dtype=np.float32)
+    L.orc_hit_triangles(len(o), tri12.ctypes.data, o.ctypes.data, d.ctypes.data, hit.ctypes.data, t.ctypes.data)
+    return hit.astype(bool), t
 
 
 class PostOracle:

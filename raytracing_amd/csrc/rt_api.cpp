@@ -28,6 +28,7 @@ void LaunchReduceTally(hipStream_t st, uint32_t* tally, uint32_t nTiles, unsigne
 void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t width, uint32_t height, uint32_t tilesX, uint32_t world,
                   uint32_t shardTiles, bool toTiled);
 void LaunchRetile(hipStream_t st, const void* gathered, void* tiled, uint32_t nTiles, uint32_t world, uint32_t shardTiles);
+void LaunchProbeTriangles(hipStream_t st, const void* tris, const float* o3, const float* d3, uint32_t n, uint32_t* hitT);
 int RunPostprocess(hipStream_t st, const void* accumImage, uint32_t tilesX, uint32_t width, uint32_t height, int bloomOn, void** scratch,
                    float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
 int ReadDisplay(hipStream_t st, void** scratch, uint32_t width, uint32_t height, float* rgbaOutHost, uint8_t* rgb8OutHost, std::string& err);
@@ -235,6 +236,22 @@ void rt_destroy(rt_context* c) {
     delete c;
 }
 
+namespace {
+// One triangle of the reference's buffer (three corners, xyz0 each) as the 48-byte device record: first corner and the
+// two edges, subtracted here once the way the shader subtracts them per test (Fragment.glsl:212-213).
+TriRec MakeTriRec(const float* p, int32_t material) {
+    TriRec t;
+    float v0[3] = {Flush(p[0]), Flush(p[1]), Flush(p[2])};
+    float e1[3], e2[3];
+    for (int k = 0; k < 3; ++k) { e1[k] = Flush(Flush(p[4 + k]) - v0[k]); e2[k] = Flush(Flush(p[8 + k]) - v0[k]); }
+    t.v0[0] = v0[0]; t.v0[1] = v0[1]; t.v0[2] = v0[2];
+    t.e1x = e1[0]; t.e1y = e1[1]; t.e1z = e1[2];
+    t.e2x = e2[0]; t.e2y = e2[1]; t.e2z = e2[2];
+    t.material = material; t.pad[0] = t.pad[1] = 0;
+    return t;
+}
+}  // namespace
+
 int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, uint32_t nTri, const float* node8, uint32_t nNode) try {
     if (!c) return RT_ERR_INVALID;
     if ((nTri && (!tri12 || !matIdx)) || (nNode && !node8)) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: NULL array");
@@ -316,17 +333,7 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
         if (matIdx[i] < 0 || matIdx[i] >= kMaxMaterials) return Fail(c, RT_ERR_INVALID, "rt_scene_upload: triangle %u uses material slot %d (valid: 0..15)", i, matIdx[i]);
 
     std::vector<TriRec> tris(nTri);
-    for (uint32_t i = 0; i < nTri; ++i) {
-        const float* p = tri12 + (size_t)i * 12;
-        TriRec& t = tris[i];
-        float v0[3] = {Flush(p[0]), Flush(p[1]), Flush(p[2])};
-        float e1[3], e2[3];
-        for (int k = 0; k < 3; ++k) { e1[k] = Flush(Flush(p[4 + k]) - v0[k]); e2[k] = Flush(Flush(p[8 + k]) - v0[k]); }
-        t.v0[0] = v0[0]; t.v0[1] = v0[1]; t.v0[2] = v0[2];
-        t.e1x = e1[0]; t.e1y = e1[1]; t.e1z = e1[2];
-        t.e2x = e2[0]; t.e2y = e2[1]; t.e2z = e2[2];
-        t.material = matIdx[i]; t.pad[0] = t.pad[1] = 0;
-    }
+    for (uint32_t i = 0; i < nTri; ++i) tris[i] = MakeTriRec(tri12 + (size_t)i * 12, matIdx[i]);
 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // from here until the new arrays are in place the context has no scene (a failed allocation must not leave
@@ -614,6 +621,40 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) try {
         }
     // the id pass ran the tallies too; drop its own so that the counters describe rt_render only
     HIP_TRY(c, hipMemsetAsync(c->dTally, 0, (size_t)kCounterSlots * c->maxWaves * sizeof(uint32_t), c->stream));
+    return RT_OK;
+} catch (const std::exception& e) {
+    return Fail(c, RT_ERR_DEVICE, "out of host memory or internal error: %s", e.what());
+}
+
+int rt_probe_triangles(rt_context* c, uint32_t n, const float* tri12, const float* origins3, const float* directions3, uint8_t* hitOut,
+                       float* tOut) try {
+    if (!c) return RT_ERR_INVALID;
+    if (n && (!tri12 || !origins3 || !directions3 || !hitOut || !tOut)) return Fail(c, RT_ERR_INVALID, "rt_probe_triangles: NULL argument");
+    if (n > (1u << 24)) return Fail(c, RT_ERR_UNSUPPORTED, "rt_probe_triangles: %u pairs (limit %u)", n, 1u << 24);
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<TriRec> tris(n);
+    for (uint32_t i = 0; i < n; ++i) tris[i] = MakeTriRec(tri12 + (size_t)i * 12, 0);
+    std::vector<uint32_t> hitT(n);
+    const size_t triBytes = sizeof(TriRec) * n, vecBytes = sizeof(float) * 3 * n, outBytes = sizeof(uint32_t) * n;
+    char* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, triBytes + 2 * vecBytes + outBytes));
+    float* dO = reinterpret_cast<float*>(d + triBytes);
+    float* dD = reinterpret_cast<float*>(d + triBytes + vecBytes);
+    uint32_t* dOut = reinterpret_cast<uint32_t*>(d + triBytes + 2 * vecBytes);
+    hipError_t e = hipMemcpyAsync(d, tris.data(), triBytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dO, origins3, vecBytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dD, directions3, vecBytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { LaunchProbeTriangles(c->stream, d, dO, dD, n, dOut); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(hitT.data(), dOut, outBytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIP_TRY(c, e);
+    for (uint32_t i = 0; i < n; ++i) {
+        hitOut[i] = hitT[i] != 0xffffffffu;
+        const uint32_t bits = hitOut[i] ? hitT[i] : 0u;
+        std::memcpy(tOut + i, &bits, sizeof bits);
+    }
     return RT_OK;
 } catch (const std::exception& e) {
     return Fail(c, RT_ERR_DEVICE, "out of host memory or internal error: %s", e.what());

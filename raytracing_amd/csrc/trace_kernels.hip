@@ -414,11 +414,16 @@ __device__ __forceinline__ bool hit_triangle(const Ray& r, float4 a, float4 b, f
     float det = dot3(e1, h);
     float invDet = rcp_exact(det);
     V3 s = r.o - v0;
-    float u = invDet * dot3(s, h);
+    const float dsh = dot3(s, h);
+    float u = invDet * dsh;
     V3 q = cross3(s, e1);
-    float v = invDet * dot3(r.d, q);
+    const float ddq = dot3(r.d, q);
+    float v = invDet * ddq;
     t = invDet * dot3(e2, q);
-    bool reject = (fabsf(det) < 1e-8f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (u + v > 1.0f) | (t < 0.0001f);
+    // The shader's `u + v` adds two products that share invDet; the shader compiler in front of llvmpipe factors it
+    // into invDet * (dot(s,h) + dot(d,q)), which now and then differs in the last bit: that decides hits lying exactly
+    // on an edge two triangles share. u and v on their own are compared as written.
+    bool reject = (fabsf(det) < 1e-8f) | (u < 0.0f) | (u > 1.0f) | (v < 0.0f) | (invDet * (dsh + ddq) > 1.0f) | (t < 0.0001f);
     return !reject;
 }
 
@@ -835,6 +840,19 @@ __global__ void retile_kernel(const float4* __restrict__ gathered, float4* __res
     tiled[i] = gathered[((size_t)(tile % world) * shardTiles + tile / world) * 64u + lane];
 }
 
+// The tracer's ray/triangle test on independent (triangle, ray) pairs, one pair per lane: the same hit_triangle, fed
+// with the same 48-byte records, that the leaf body runs. hitT[i] = bit pattern of t on a hit, 0xffffffff on a miss.
+__global__ void probe_triangles_kernel(const TriRec* __restrict__ tris, const float* __restrict__ o3, const float* __restrict__ d3, uint32_t n,
+                                       uint32_t* __restrict__ hitT) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4* T = reinterpret_cast<const float4*>(tris + i);
+    const Ray r = MakeRay(mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]));
+    float t = 0.0f;
+    const bool hit = hit_triangle(r, T[0], T[1], T[2].x, t);
+    hitT[i] = hit ? __float_as_uint(t) : 0xffffffffu;
+}
+
 }  // namespace
 
 
@@ -896,6 +914,10 @@ void LaunchUntile(hipStream_t st, const void* tiled, void* linear, uint32_t widt
 void LaunchRetile(hipStream_t st, const void* gathered, void* tiled, uint32_t nTiles, uint32_t world, uint32_t shardTiles) {
     hipLaunchKernelGGL(retile_kernel, dim3((nTiles * 64u + 255u) / 256u), dim3(256), 0, st, static_cast<const float4*>(gathered), static_cast<float4*>(tiled),
                        nTiles, world, shardTiles);
+}
+
+void LaunchProbeTriangles(hipStream_t st, const void* tris, const float* o3, const float* d3, uint32_t n, uint32_t* hitT) {
+    hipLaunchKernelGGL(probe_triangles_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, static_cast<const TriRec*>(tris), o3, d3, n, hitT);
 }
 
 }  // namespace rtd

@@ -190,6 +190,18 @@ class Renderer:
         self._ck(self.L.rt_primary_ids(self.h, s.ctypes.data, out.ctypes.data), "rt_primary_ids")
         return out
 
+    def probe_triangles(self, tri12, origins, directions):
+        """The tracer's ray/triangle test on n independent (triangle, ray) pairs: (hit (n,) bool, t (n,) float32)."""
+        tri12 = np.ascontiguousarray(tri12, dtype=np.float32).reshape(-1, 12)
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        if not (len(tri12) == len(o) == len(d)):
+            raise ValueError("probe_triangles: %d triangles, %d origins, %d directions" % (len(tri12), len(o), len(d)))
+        hit, t = np.zeros(len(o), dtype=np.uint8), np.zeros(len(o), dtype=np.float32)
+        self._ck(self.L.rt_probe_triangles(self.h, len(o), tri12.ctypes.data, o.ctypes.data, d.ctypes.data, hit.ctypes.data, t.ctypes.data),
+                 "rt_probe_triangles")
+        return hit.astype(bool), t
+
     def postprocess(self, bloom_on=True, want_rgb8=True):
         rgba = np.empty((self.H, self.W, 4), dtype=np.float32)
         rgb8 = np.empty((self.H, self.W, 3), dtype=np.uint8) if want_rgb8 else None

@@ -317,3 +317,41 @@ def test_deepest_tree_the_stack_can_hold_bit_exact():
     with pytest.raises(ra.RtError, match="63"):
         g.set_scene(*deeper)
     g.close()
+
+
+def test_triangle_edges_bit_exact():
+    """The device's ray/triangle test on rays aimed at triangle edges: against the llvmpipe fixture (the reference's own
+    hitTriangle), and against the CPU restatement on a fresh million of such pairs. Bar: same hit, same bits of t."""
+    import os
+    from rt_oracle import hit_triangles
+    t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "triangle_edges.npz"))
+    g = ra.Renderer(64, 64)
+    hit, dist = g.probe_triangles(t["tri12"], t["origins"], t["directions"])
+    assert (hit == t["hit"]).all(), int((hit != t["hit"]).sum())
+    assert (bits(dist) == bits(t["t"])).all()
+
+    rng = np.random.default_rng(77)
+    n = 1 << 20
+    v0 = (np.round(rng.uniform(-8, 8, (n, 3)) * 2) / 2).astype(np.float32)
+    e1, e2 = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    axis = rng.integers(0, 3, n)
+    rows = np.arange(n)
+    e1[rows, (axis + 1) % 3] = np.round(rng.uniform(1, 24, n)) / 2
+    e2[rows, (axis + 2) % 3] = np.round(rng.uniform(1, 24, n)) / 2
+    free = rng.random(n) < 0.5                                   # the other half: triangles in general position
+    e1[free], e2[free] = rng.uniform(-12, 12, (int(free.sum()), 3)), rng.uniform(-12, 12, (int(free.sum()), 3))
+    v1, v2 = v0 + e1, v0 + e2
+    s = rng.random((n, 1)).astype(np.float32)
+    target = v1 + s * (v2 - v1)                                  # on the edge opposite the first corner: u + v = 1
+    origin = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    d = (target - origin).astype(np.float64)
+    d = (d / np.sqrt((d * d).sum(-1, keepdims=True))).astype(np.float32)
+    tri12 = np.zeros((n, 12), np.float32)
+    tri12[:, 0:3], tri12[:, 4:7], tri12[:, 8:11] = v0, v1, v2
+    hit_g, t_g = g.probe_triangles(tri12, origin, d)
+    hit_o, t_o = hit_triangles(tri12, origin, d)
+    assert 0.2 < hit_o.mean() < 0.8
+    assert (hit_g == hit_o).all(), int((hit_g != hit_o).sum())
+    assert (bits(t_g) == bits(t_o)).all()
+    assert g.probe_triangles(np.zeros((0, 12)), np.zeros((0, 3)), np.zeros((0, 3)))[0].shape == (0,)
+    g.close()

@@ -106,3 +106,17 @@ def test_rotated_sky_lookup_matches_llvmpipe():
     o.set_skybox(sky)
     bad = sum(int((bits(o.sample_sky_rotated(d)) != bits(want)).any()) for d, want in zip(t["dirs"], t["colours"]))
     assert len(t["dirs"]) > 4000 and bad == 0, bad
+
+
+def test_triangle_edges_match_llvmpipe():
+    """hitTriangle of the CPU restatement against the reference's own hitTriangle run on llvmpipe, for rays aimed at
+    the edges of their triangle, where the last bit of u, v and u + v decides between hit and miss. llvmpipe's shader
+    compiler evaluates u + v as invDet * (dot(s,h) + dot(direction,q)); as written in the source it would disagree on
+    some of these cases, which on closed meshes lets rays through the edge two triangles share."""
+    from rt_oracle import hit_triangles
+    t = np.load(os.path.join(GOLDEN, "triangle_edges.npz"))
+    hit, dist = hit_triangles(t["tri12"], t["origins"], t["directions"])
+    n = len(t["hit"])
+    assert n >= 8000 and 0.3 < t["hit"].mean() < 0.9
+    assert (hit == t["hit"]).all(), int((hit != t["hit"]).sum())
+    assert (bits(dist) == bits(t["t"])).all()
