@@ -29,16 +29,26 @@ ap.add_argument("--width", type=int, default=960)
 ap.add_argument("--height", type=int, default=540)
 ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--frames", type=int, default=5)
+ap.add_argument("--camera", default="", help="px,py,pz,fx,fy,fz: position and facing (normalised here); default = the reference's start pose")
+ap.add_argument("--fov", type=float, default=120.0, help="field of view in degrees (the reference uses 120, and 90 with the C key)")
+ap.add_argument("--skip-seeds", type=int, default=0, help="start this many draws into the seed stream")
 args = ap.parse_args()
 W, H = args.width, args.height
 sc = make_scene(args.scene, **({"target_tris": args.tris} if args.tris else {}))
-noise, sky, seeds = scenes.noise_texture(), scenes.sky_cubemap(), scenes.frame_seeds(args.frames)
+noise, sky, seeds = scenes.noise_texture(), scenes.sky_cubemap(), scenes.frame_seeds(args.frames + args.skip_seeds)[args.skip_seeds:]
+camera = dict(DEFAULT_CAMERA)
+if args.camera:
+    c = np.array([float(x) for x in args.camera.split(",")], np.float32)
+    facing = c[3:6] / np.float32(np.sqrt((c[3:6].astype(np.float64) ** 2).sum()))
+    camera.update(position=tuple(float(x) for x in c[:3]), facing=tuple(float(x) for x in facing))
+fov = np.float32(args.fov * 0.01745329251994329576923690768489)
+camera.update(fov=float(fov), viewport_width=float(np.float32(2.0 * np.tan(float(fov) / 2.0))))
 
 
 def setup(r):
     r.set_scene(sc.tri12, sc.matidx, sc.node8)
     r.set_materials(sc.materials)
-    r.set_camera(**DEFAULT_CAMERA)
+    r.set_camera(**camera)
     r.set_noise(noise)
     r.set_skybox(sky)
     r.set_bounce_limit(args.bounces)
