@@ -194,6 +194,7 @@ int rt_create(int device, uint32_t width, uint32_t height, rt_context** out) {
     sp.vpW = (float)(2.0 * 1.0 * std::tan((float)(120 * 0.01745329251994329576923690768489) / 2.0));   // src/Camera.cpp:14,19
     const float a = (float)(-3.1415 / 2);                 // Fragment.glsl:406
     sp.skyCos = std::cos(a); sp.skySin = std::sin(a);
+    { volatile float rest = 1.0f - sp.skyCos; volatile float sum = sp.skyCos + rest; sp.skyXScale = sum; }   // two fp32 roundings, as on the device
     hipError_t se = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return Fail(nullptr, RT_ERR_DEVICE, "hipStreamCreate: %s", hipGetErrorString(se)); }
     c->stream = c->ownStream;

@@ -82,6 +82,7 @@ struct SceneParams {
     float camPos[3], camFacing[3];
     float vpW, vpD;
     float skyCos, skySin;        // cos/sin of the constant sky rotation angle, Fragment.glsl:406,411
+    float skyXScale;             // skyCos + (1 - skyCos): what the rotation multiplies the x component by
     uint32_t width, height, tilesX, tilesY;
     uint32_t shardRank, shardWorld, shardTiles;   // this context renders global tile j*world+rank
 };

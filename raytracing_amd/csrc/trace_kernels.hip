@@ -77,6 +77,21 @@ __device__ __forceinline__ uint32_t Hash(uint32_t x) {      // F:96-105
 }
 __device__ __forceinline__ uint32_t Hashf(float f) { return Hash(__float_as_uint(f)); }
 
+// Hash(i) and Hash(i + 69) for the bounce counters a path can reach in practice (F:392-393): two full-rate-quarter
+// multiplies and eight other instructions each, replaced by one 8-byte load from a table that stays in the vector L1.
+constexpr uint32_t HashConst(uint32_t x) {
+    x ^= x >> 17; x *= 0xed5ad4bbU; x ^= x >> 11; x *= 0xac4c1b51U; x ^= x >> 15; x *= 0x31848babU; x ^= x >> 14;
+    return x;
+}
+constexpr uint32_t kHashedBounces = 64;
+struct BounceHashes {
+    uint32_t v[2 * kHashedBounces];
+    constexpr BounceHashes() : v() {
+        for (uint32_t i = 0; i < kHashedBounces; ++i) { v[2 * i] = HashConst(i); v[2 * i + 1] = HashConst(i + 69u); }
+    }
+};
+__constant__ BounceHashes kBounceHashes = BounceHashes();
+
 // Products of two numbers below 2^24 (texel rows x texture width, triangle index x record size, tile quotients,
 // 8-bit channels x weights): the 24-bit multiplier gives the same 32-bit result as v_mul_lo_u32 at a quarter of its
 // issue cost.
@@ -168,11 +183,12 @@ __device__ __forceinline__ void coord_clamp(float c, int n, int& i0, int& i1, in
 
 // texture(u_Skybox, RotateAroundAxis(dir, (1,0,0), -3.1415/2)) : F:158-163,406,411
 __device__ __forceinline__ Texels fetch_sky(const SceneParams& sp, V3 dir) {
-    const V3 k = mk(1.0f, 0.0f, 0.0f);
-    V3 d = (dir * sp.skyCos + cross3(k, dir) * sp.skySin) + (k * dot3(k, dir)) * (1.0f - sp.skyCos);
-    // With the axis a constant, the shader compiler in front of llvmpipe factors the x component,
-    // dir.x * cos + dir.x * (1 - cos), into dir.x * (cos + (1 - cos)); the two differ in the last bit now and then.
-    d.x = dir.x * (sp.skyCos + (1.0f - sp.skyCos));
+    // Rodrigues' formula with the axis (1,0,0) written out: v*cos + (k x v)*sin + k*dot(k,v)*(1-cos). The terms that
+    // are products with the axis' zeros only add signed zeros, which can change nothing but the sign of a zero
+    // component, and the cube lookup does not distinguish those. With the axis a constant, the shader compiler in
+    // front of llvmpipe factors the x component, dir.x * cos + dir.x * (1 - cos), into dir.x * (cos + (1 - cos)):
+    // the two differ in the last bit now and then, and the factor comes ready from the host.
+    V3 d = mk(dir.x * sp.skyXScale, dir.y * sp.skyCos + (-dir.z) * sp.skySin, dir.z * sp.skyCos + dir.y * sp.skySin);
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     int axis = (az >= fmaxf(ax, ay)) ? 2 : (ax > ay ? 0 : 1);
     float ma = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
@@ -614,8 +630,15 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                     if (COUNT && hitAnything) tl.hits++;
                     const int i = L.bounce;
                     // F:391-394
-                    uint32_t sx = Hashf(L.ray.o.x + L.ray.d.y) + Hash((uint32_t)i) + fp.hashX;
-                    uint32_t sy = Hashf(L.ray.o.y + L.ray.d.z) + Hash((uint32_t)(i + 69)) + fp.hashY;
+                    uint32_t hi, hj;
+                    if (__builtin_expect((uint32_t)i < kHashedBounces, 1)) {
+                        const uint2 h = *reinterpret_cast<const uint2*>(&kBounceHashes.v[2 * i]);
+                        hi = h.x; hj = h.y;
+                    } else {
+                        hi = Hash((uint32_t)i); hj = Hash((uint32_t)(i + 69));
+                    }
+                    uint32_t sx = Hashf(L.ray.o.x + L.ray.d.y) + hi + fp.hashX;
+                    uint32_t sy = Hashf(L.ray.o.y + L.ray.d.z) + hj + fp.hashY;
                     float fsx = (float)sx, fsy = (float)sy;
                     float seedx = div_by_uniform(fsx - nresx * floorf(div_by_uniform(fsx, nresx, rnresx)), nresx, rnresx);
                     float seedy = div_by_uniform(fsy - nresy * floorf(div_by_uniform(fsy, nresy, rnresy)), nresy, rnresy);
@@ -644,7 +667,8 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                         V3 n = normalize3(cross3(e1, e2));
                         const bool frontFace = dot3(L.ray.d, n) < 0.0f;
                         hitNormal = frontFace ? n : -n;
-                        const MaterialRec m = lds_mat[__float_as_int(tc_y)];
+                        const MaterialRec m = *reinterpret_cast<const MaterialRec*>(reinterpret_cast<const char*>(lds_mat) +
+                                                                                    mul24((uint32_t)__float_as_int(tc_y), (uint32_t)sizeof(MaterialRec)));
                         V3 hitColour = mk(m.colour[0], m.colour[1], m.colour[2]);
                         if (m.isLight) {
                             result = (L.throughput * hitColour) * m.transparency;   // F:415-418
