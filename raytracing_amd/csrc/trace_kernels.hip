@@ -568,6 +568,13 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
         const bool runFeed = nFeed >= RT_SHADE_AT, runLeaf = !runFeed && nLeaf >= RT_LEAF_AT;
 
         if (COUNT) rc.start();
+#ifdef RT_PROBE_IDLE
+        // Measurement build only: what the lanes that sit out an interior round are waiting for. Added on top of four
+        // of the ordinary tallies by lane 0 (subtract the tallies of an ordinary build).
+        if (COUNT && nInt == most && !runFeed && !runLeaf && lane == 0) {
+            tl.sky += 1u; tl.noise += (uint32_t)nInt; tl.hits += (uint32_t)nLeaf; tl.paths += (uint32_t)nFeed;
+        }
+#endif
         if (nInt == most && !runFeed && !runLeaf) {
             // the hot loop: stay in it while most of the lanes that entered are still descending
             int steps = 0;
