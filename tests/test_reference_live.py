@@ -1,0 +1,37 @@
+"""The CPU restatement against the LIVE reference: the reference's unmodified tracer shader run on headless Mesa
+llvmpipe (oracle/glsl_ref), on scenes and cameras that are not among the committed fixtures. Runs only where the
+reference's sources and the harness built from them (oracle/_ref/libglref.so) are present, i.e. in the build container;
+skipped elsewhere (the reference does not travel). Bar: primary-hit ids and distances and every frame's radiance bit
+for bit (oracle/compare_reference.py exits non-zero on any difference)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = os.environ.get("RT_REFERENCE_DIR", "/root/reference")
+HAVE = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libglref.so")) and os.path.exists(os.path.join(REFERENCE, "src", "shaders", "Fragment.glsl"))
+
+pytestmark = pytest.mark.skipif(not HAVE, reason="needs the reference's sources and oracle/_ref (build container only)")
+
+CASES = [
+    # scene, triangles, width, height, bounce limit, frames, camera, fov
+    ("lightbox", 0, 200, 120, 4, 6, "0.5,0.3,0.2,1,0.4,-0.3", 120),
+    ("sponza_like", 9000, 176, 100, 8, 4, "1.0,0.5,0.4,-1,0.2,0.1", 90),
+    ("dragon_like", 7000, 144, 90, 16, 3, "", 120),
+    ("teapot_like", 5000, 150, 84, 2, 3, "1.5,-2,0.7,0.8,0.55,-0.2", 120),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_restatement_equals_live_shader(case):
+    scene, tris, w, h, bounces, frames, camera, fov = case
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "compare_reference.py"), "--scene", scene, "--tris", str(tris), "--width", str(w),
+           "--height", str(h), "--bounces", str(bounces), "--frames", str(frames), "--fov", str(fov), "--skip-seeds", "7"]
+    if camera:
+        cmd += ["--camera=" + camera]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "triangle ids differing: 0; hit distances differing: 0" in run.stdout
+    assert run.stdout.count("pixels differ") == frames
