@@ -832,6 +832,8 @@ struct rt_group {
     std::vector<ncclComm_t> comms;
     void* dGathered = nullptr;           // on devices[0]: world shards back to back
     hipEvent_t gathered = nullptr;       // recorded on rank 0's stream behind the receives
+    hipEvent_t assembled = nullptr;      // recorded on the root's stream behind the assembly (the next receives wait for it)
+    bool haveAssembled = false;
     size_t shardFloats = 0;
     std::string error;
 };
@@ -859,6 +861,7 @@ void rt_group_destroy(rt_group* g) {
         if (g->comms[r] && nc.ok) { (void)hipSetDevice(g->devices[r]); (void)nc.CommDestroy(g->comms[r]); }
     if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
     if (g->gathered) (void)hipEventDestroy(g->gathered);
+    if (g->assembled) (void)hipEventDestroy(g->assembled);
     if (g->dGathered) (void)hipFree(g->dGathered);
     for (rt_context* c : g->ranks) rt_destroy(c);
     rt_destroy(g->root);
@@ -889,7 +892,8 @@ int rt_group_create(const int* devices, uint32_t nDevices, uint32_t width, uint3
     if (rc != RT_OK) return fail(rc, "rt_group_create: root context");
     g->shardFloats = (size_t)g->ranks[0]->sp.shardTiles * 64 * 4;
     if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&g->dGathered, g->shardFloats * sizeof(float) * nDevices) != hipSuccess ||
-        hipEventCreateWithFlags(&g->gathered, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&g->gathered, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->assembled, hipEventDisableTiming) != hipSuccess) {
         g_globalError = "device memory for the gathered shards";
         return fail(RT_ERR_DEVICE, "rt_group_create");
     }
@@ -919,6 +923,12 @@ int rt_group_gather(rt_group* g) {
     if (!g) return RT_ERR_INVALID;
     Rccl& nc = LoadRccl();
     const uint32_t world = (uint32_t)g->ranks.size();
+    // the previous call's assembly may still be reading the receive buffer on the root's stream
+    if (g->haveAssembled) {
+        HIP_TRY(g->root, hipSetDevice(g->devices[0]));
+        if (hipStreamWaitEvent(g->ranks[0]->stream, g->assembled, 0) != hipSuccess)
+            return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: ordering the receives behind the previous assembly failed");
+    }
     // One group call: every rank sends its shard (behind its frames, on its own stream) to rank 0, which receives them
     // back to back. Every peer has its own xGMI link to rank 0, so the sends run side by side.
     ncclResult_t nr = nc.GroupStart();
@@ -935,6 +945,8 @@ int rt_group_gather(rt_group* g) {
         return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: ordering the assembly behind the receives failed");
     int rc = rt_accum_assemble(g->root, g->dGathered, world);
     if (rc != RT_OK) return GroupFail(g, rc, "rt_group_gather: %s", rt_last_error(g->root));
+    if (hipEventRecord(g->assembled, g->root->stream) != hipSuccess) return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: hipEventRecord failed");
+    g->haveAssembled = true;
     return RT_OK;
 }
 

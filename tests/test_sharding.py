@@ -134,7 +134,7 @@ def test_group_of_one_device_gathers_over_rccl_and_equals_unsharded():
     from util import differing_pixels, make_scene, setup
     W, H = 200, 120
     sc = make_scene("sponza_like", target_tris=6000)
-    noise, sky, seeds = scenes.noise_texture(64, 48), scenes.sky_cubemap(32), scenes.frame_seeds(5)
+    noise, sky, seeds = scenes.noise_texture(64, 48), scenes.sky_cubemap(32), scenes.frame_seeds(11)
     g = ra.Group([0], W, H)
     assert len(g.ranks) == 1
     for r in g.ranks:
@@ -145,10 +145,18 @@ def test_group_of_one_device_gathers_over_rccl_and_equals_unsharded():
     g.gather()
     whole.render(0, seeds[:3])
     assert differing_pixels(g.root.read_accum(), whole.read_accum()) == 0
-    g.render(3, seeds[3:])
+    g.render(3, seeds[3:5])
     g.gather()
     g.sync()
-    whole.render(3, seeds[3:])
+    whole.render(3, seeds[3:5])
+    assert differing_pixels(g.root.read_accum(), whole.read_accum()) == 0
+    # six frames, each gathered, all queued without the host waiting in between: every receive has to wait for the
+    # assembly that still reads the receive buffer
+    for k in range(5, 11):
+        g.render(k, seeds[k:k + 1])
+        g.gather()
+    g.sync()
+    whole.render(5, seeds[5:11])
     assert differing_pixels(g.root.read_accum(), whole.read_accum()) == 0
     rgba, rgb8 = g.root.postprocess(True)              # the root context is an ordinary one: bloom chain on the gathered image
     want_rgba, want_rgb8 = whole.postprocess(True)
