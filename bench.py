@@ -226,20 +226,27 @@ def main():
             gathered = [list(f.chunk(world)) for f in flats]     # the gather writes the shards back to back
             root = ra.Renderer(W, H, device=device)              # unsharded context that assembles the image
 
+    # With nccl the whole exchange is ordered on the device: the renderers run on torch streams, so that torch events can
+    # order them against the collective's stream, and the host never waits inside the loop (it only queues).
+    #   tracer stream  rs : render k, [wait: gather k-2 done] export shard into stage[k&1], event `exported`
+    #   torch stream      : wait exported, [rank 0: wait assembly k-2], gather k (its own stream, after this one), event `gathered`
+    #   assembly stream as: (rank 0) wait gathered, scatter flats[k&1] into the image, event `assembled`
+    on_device = sharded and backend == "nccl"
+    rs = as_ = None
+    gathered_ev = [None, None]
+    assembled_ev = [None, None]
+    if on_device:
+        rs = torch.cuda.Stream()
+        r.set_stream(rs.cuda_stream)
+        if root is not None:
+            as_ = torch.cuda.Stream()
+            root.set_stream(as_.cuda_stream)
+
     def finish(k):
-        """Completes the exchange of frame k: waits for its gather, rank 0 scatters the shards into the image."""
+        """(host-staged rehearsal only) Completes the exchange of frame k: rank 0 scatters the shards into the image."""
         b = k & 1
         if pending[b] is None:
             return
-        if backend == "nccl":
-            # wait() only makes torch's current stream wait for the gather; the host has to know that it is over,
-            # on every rank: the send buffer of this parity is written again by the renderer's own stream two frames
-            # on, and rank 0 reads the received shards on yet another stream. Waiting for the gather alone (it was
-            # started a frame ago) instead of the whole device lets the frame being traced keep running.
-            pending[b].wait()
-            done = torch.cuda.Event()
-            done.record()
-            done.synchronize()
         if rank == 0:
             root.assemble(flats[b].data_ptr(), world)
         pending[b] = None
@@ -249,20 +256,37 @@ def main():
         if not sharded:
             return
         b = k & 1
-        r.export_shard(stage[b].data_ptr())      # queued behind the frame on the renderer's stream
-        finish(k - 1)                            # the previous frame's exchange overlapped with this frame's tracing
+        if on_device:
+            if gathered_ev[b] is not None:
+                rs.wait_event(gathered_ev[b])        # stage[b] was the send buffer of gather k-2
+            r.export_shard(stage[b].data_ptr())      # behind the frame on the tracer's stream; frame k+1 follows at once
+            exported = torch.cuda.Event()
+            exported.record(rs)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(exported)
+            if assembled_ev[b] is not None:
+                cur.wait_event(assembled_ev[b])      # flats[b] was read by the assembly of frame k-2
+            work = dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+            work.wait()                              # the current stream (not the host) waits for the collective
+            gathered_ev[b] = torch.cuda.Event()
+            gathered_ev[b].record(cur)
+            if rank == 0:
+                as_.wait_event(gathered_ev[b])
+                root.assemble(flats[b].data_ptr(), world)
+                assembled_ev[b] = torch.cuda.Event()
+                assembled_ev[b].record(as_)
+            return
+        r.export_shard(stage[b].data_ptr())
+        finish(k - 1)
         r.sync()
         if root is not None:
-            root.sync()                          # the receive buffer of this parity was read by the assembly of frame k-2
-        if backend == "nccl":
-            pending[b] = dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
-        else:
-            host = stage[b].cpu()
-            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-            dist.gather(host, parts, dst=0)
-            if rank == 0:
-                flats[b].copy_(torch.cat(parts))
-            pending[b] = True
+            root.sync()
+        host = stage[b].cpu()
+        parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, parts, dst=0)
+        if rank == 0:
+            flats[b].copy_(torch.cat(parts))
+        pending[b] = True
 
     def fence():
         finish(0)
@@ -368,6 +392,10 @@ def main():
         if rec and not sharded:
             out["llvmpipe_recorded"] = rec
         print(json.dumps(out), flush=True)
+    if on_device:
+        r.set_stream(None)          # back to the contexts' own streams before torch's go away
+        if root is not None:
+            root.set_stream(None)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
