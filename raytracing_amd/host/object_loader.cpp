@@ -1,5 +1,8 @@
 #include "object_loader.h"
 
+#include <algorithm>
+#include <cerrno>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,10 +58,21 @@ public:
         if (failed_) return false;
         Skip();
         char* end = nullptr;
+        errno = 0;
         long v = std::strtol(p_, &end, 10);
         if (end == p_) { failed_ = true; out = 0; return false; }
-        p_ = end; out = (int)v;
+        p_ = end;
+        // a number that does not fit an int fails the read and leaves the nearest limit, as `istream >> int` does
+        if (errno == ERANGE || v > INT_MAX || v < INT_MIN) { failed_ = true; out = v < 0 ? INT_MIN : INT_MAX; return false; }
+        out = (int)v;
         return true;
+    }
+    // An upper bound on how many more items of at least `minBytes` characters each the text can hold: what a count
+    // read from the file is cut down to before memory is set aside for it.
+    size_t RoomFor(long count, size_t minBytes) const {
+        if (count <= 0) return 0;
+        const size_t left = buf_.size() - (size_t)(p_ - buf_.c_str());
+        return std::min<size_t>((size_t)count, left / minBytes + 1);
     }
 
 private:
@@ -126,7 +140,7 @@ bool ReadHeaderAndMaterial(Tokens& in, Placement& place, Material& material, std
 bool ReadRawTriangles(Tokens& in, const Placement& place, int slot, std::vector<Triangle>& tris, std::string* msg) {
     int n = 0;
     in.Int(n);
-    tris.reserve(n > 0 ? (size_t)n : 0);
+    tris.reserve(in.RoomFor(n, 18));          // nine numbers and their separators
     for (int i = 0; i < n; ++i) {
         Vec3 a, b, c;
         bool ok = in.Float(a.x) && in.Float(a.y) && in.Float(a.z) && in.Float(b.x) && in.Float(b.y) && in.Float(b.z) &&
@@ -144,14 +158,14 @@ bool ReadOff(Tokens& in, const Placement& place, int slot, std::vector<Triangle>
     int nv, nf, ne;
     if (!(in.Int(nv) && in.Int(nf) && in.Int(ne))) { if (msg) *msg = "failed to read OFF counts"; return false; }
     std::vector<Vec3> verts;
-    verts.reserve(nv > 0 ? (size_t)nv : 0);
+    verts.reserve(in.RoomFor(nv, 6));
     for (int i = 0; i < nv; ++i) {
         Vec3 v;
         if (!(in.Float(v.x) && in.Float(v.y) && in.Float(v.z))) { if (msg) *msg = "failed to read vertex " + std::to_string(i + 1); return false; }
         verts.push_back(place.Apply(v));
     }
     if (nf != 0) {
-        tris.reserve((size_t)nf);
+        tris.reserve(in.RoomFor(nf, 8));
         for (int i = 0; i < nf; ++i) {
             int k, a, b, c;
             if (!(in.Int(k) && in.Int(a) && in.Int(b) && in.Int(c))) { if (msg) *msg = "failed to read face " + std::to_string(i + 1); return false; }
@@ -167,7 +181,7 @@ bool ReadOff(Tokens& in, const Placement& place, int slot, std::vector<Triangle>
     const float h = 0.02f * 0.5f;
     static const int kFaces[12][3] = {{0, 1, 2}, {0, 2, 3}, {4, 5, 6}, {4, 6, 7}, {0, 1, 5}, {0, 5, 4},
                                       {3, 2, 6}, {3, 6, 7}, {0, 3, 7}, {0, 7, 4}, {1, 2, 6}, {1, 6, 5}};
-    tris.reserve((size_t)nv * 12);
+    tris.reserve(verts.size() * 12);
     for (const Vec3& ctr : verts) {
         const Vec3 corner[8] = {ctr + Vec3(-h, -h, -h), ctr + Vec3(h, -h, -h), ctr + Vec3(h, h, -h), ctr + Vec3(-h, h, -h),
                                 ctr + Vec3(-h, -h, h),  ctr + Vec3(h, -h, h),  ctr + Vec3(h, h, h),  ctr + Vec3(-h, h, h)};

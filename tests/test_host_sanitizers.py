@@ -1,0 +1,48 @@
+"""The host-side readers (object files, scene cache, PNG, INI) under AddressSanitizer and UndefinedBehaviorSanitizer:
+tests/host_sanitize_main.cpp is built from the host sources with g++ -fsanitize=address,undefined and run on the good
+files, on truncations of them and on a few thousand randomly damaged copies. Host code only (no GPU code is built with
+sanitizers). Skipped where g++ has no sanitizer runtime."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "raytracing_amd", "host")
+SOURCES = ["bvh_tree.cpp", "object_loader.cpp", "scene_data.cpp", "scene_cache.cpp", "config_parser.cpp", "image_io.cpp"]
+
+
+def write_png(path, rgb):
+    h, w, _ = rgb.shape
+    raw = b"".join(b"\x00" + rgb[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_host_readers_survive_damaged_files_under_sanitizers(tmp_path):
+    exe = str(tmp_path / "host_sanitize")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-I" + HOST, "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "host_sanitize_main.cpp")] + \
+          [os.path.join(HOST, s) for s in SOURCES] + ["-lpthread", "-lz"]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and ("asan" in build.stderr or "ubsan" in build.stderr or "sanitize" in build.stderr):
+        pytest.skip("g++ cannot link the sanitizer runtimes here")
+    assert build.returncode == 0, build.stderr[-3000:]
+    png = str(tmp_path / "seed.png")
+    write_png(png, np.random.default_rng(1).integers(0, 256, (13, 17, 3), dtype=np.uint8))
+    ini = str(tmp_path / "seed.ini")
+    with open(ini, "w") as f:
+        f.write("; comment\n[SkyBox]\nPath = Textures/DaylightBox/\n[Objects]\nDirectoryPath = Objects/\nFilenames = a.off, b.txt, c.txt\n[Shaders]\nCount = 0x10\n")
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    run = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "objects"), str(scratch), png, ini], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, (run.stdout[-2000:] + run.stderr[-6000:])
+    assert "host_sanitize:" in run.stdout
