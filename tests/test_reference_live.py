@@ -35,3 +35,39 @@ def test_restatement_equals_live_shader(case):
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert "triangle ids differing: 0; hit distances differing: 0" in run.stdout
     assert run.stdout.count("pixels differ") == frames
+
+
+POST_LIVE = r'''
+import sys
+import numpy as np
+ROOT = sys.argv[1]
+for p in (ROOT, ROOT + "/oracle", ROOT + "/oracle/glsl_ref", ROOT + "/tests"):
+    sys.path.insert(0, p)
+from glref import GLRef
+from reference_renderer import ReferenceRenderer
+from rt_oracle import PostOracle
+import make_golden as mg
+gl = GLRef()
+for (W, H) in ((320, 160), (200, 120), (250, 130), (123, 77)):
+    ref, po = ReferenceRenderer(W, H, gl=gl), PostOracle(W, H)
+    for frame in range(4):                       # consecutive frames: the tmp texture carries over in both
+        a = mg.boundary_safe_hdr(W, H, 90 + frame)
+        ref.write_accum(a)
+        rgba, rgb8 = ref.postprocess(True)
+        o_rgba, o_rgb8 = po.run(a)
+        d = float(np.abs(rgba[..., :3] - o_rgba[..., :3]).max())
+        codes = int(np.abs(rgb8.astype(int) - o_rgb8.astype(int)).max())
+        print("%dx%d frame %d: max abs diff %.3g, 8-bit codes %d" % (W, H, frame, d, codes))
+        assert d <= 2e-5 and codes <= 1
+print("post chain ok")
+'''
+
+
+def test_bloom_chain_restatement_equals_live_shaders(tmp_path):
+    """The bloom chain of the CPU restatement against the reference's own post shaders run on llvmpipe with main.cpp's
+    sequence of passes, at sizes other than the fixture's, four consecutive frames each. Tolerance 2e-5 absolute (llvmpipe
+    approximates pow), 8-bit output within one code."""
+    script = tmp_path / "post_live.py"
+    script.write_text(POST_LIVE)
+    run = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "post chain ok" in run.stdout, run.stdout[-2000:] + run.stderr[-2000:]
