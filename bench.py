@@ -16,6 +16,7 @@ The scene is a deterministic synthetic stand-in (the reference's Sponza.off is a
 written to and loaded from the reference's own .off/.txt formats.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -302,6 +303,12 @@ def main():
         step(k)
     fence()
     saved = r.read_accum() if (not sharded and not args.no_roofline_pass) else None
+    saved_shard = None
+    if sharded and not args.no_roofline_pass:
+        # this rank's part of the image as the timed frames will find it, for the counting replay after them
+        saved_shard = torch.empty(r.shard_tiles() * 64 * 4, dtype=torch.float32, device="cuda")
+        r.export_shard(saved_shard.data_ptr())
+        r.sync()
     r.counters(reset=True)
     r.kernel_time(reset=True)
     fence()
@@ -336,6 +343,37 @@ def main():
         rays, paths, kms_max = float(c["rays"]), float(c["paths"]), kms
 
     roofline = None
+    if sharded and saved_shard is not None:
+        # Counting replay of exactly the timed frames, every rank on its own tiles from the state saved above; the
+        # algorithmic bytes of the node are the sum over ranks, priced against the ranks' longest kernel time per step
+        # and against N times the HBM peak.
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        r.sync()
+        if hip.hipMemcpy(r.shard_device_ptr(), saved_shard.data_ptr(), saved_shard.numel() * 4, 3) != 0:
+            raise SystemExit("restoring the shard for the counting replay failed")
+        r.set_counting(True)
+        r.counters(reset=True)
+        for k in range(Wm, Wm + K):
+            r.render(k, seeds[k:k + 1])
+        r.sync()
+        ci = r.counters(reset=True)
+        r.set_counting(False)
+        assert ci["rays"] == c["rays"], "instrumented replay traced a different number of rays"
+        nb = torch.tensor([float(algorithmic_bytes(ci)), float(ci["boxes_tested"]), float(ci["tris_tested"])], dtype=torch.float64,
+                          device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(nb, op=dist.ReduceOp.SUM)
+        per_step = float(nb[0]) / K
+        step_ms = kms_max / K
+        achieved = per_step / (step_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                    "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": None,
+                    "note": "whole node: algorithmic bytes of all ranks per step over the slowest rank's kernel time per step, against %d x the HBM "
+                            "peak; as on one GPU the bytes are re-reads served by the caches (frac > 1 on one GPU), so the fraction shows how much of "
+                            "the one-GPU rate survives the sharding, not a distance from an HBM limit" % world,
+                    "kernel": "trace_kernel", "kernel_ms_per_step_slowest_rank": round(step_ms, 4),
+                    "algorithmic_bytes_per_step": int(per_step),
+                    "bytes_per_ray": round(float(nb[0]) / rays, 1), "boxes_per_ray": round(float(nb[1]) / rays, 2), "tris_per_ray": round(float(nb[2]) / rays, 2)}
     if not sharded and not args.no_roofline_pass:
         # instrumented replay of exactly the timed frames from the same accumulation state
         r.write_accum(saved)
