@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised live comparison of the CPU restatement with the reference's tracer shader on llvmpipe: random scene
-generator and size, image size, camera pose, field of view, bounce limit, frame count and position in the seed stream;
+generator and size, image size, camera pose, field of view, bounce limit (the two debug views included), frame count and position in the seed stream;
 each case is one run of oracle/compare_reference.py. Build container only. Test infrastructure, not part of the product.
 
   python3 oracle/fuzz_reference.py --cases 200 --seed 1 [--log /tmp/fuzz_reference.log]
@@ -31,7 +31,7 @@ for i in range(args.cases):
     facing = rng.standard_normal(3)
     facing[2] *= 0.5
     cmd = [sys.executable, os.path.join(HERE, "compare_reference.py"), "--scene", scene, "--tris", str(tris), "--width", str(w), "--height", str(h),
-           "--bounces", str([2, 4, 8, 16, 32][int(rng.integers(0, 5))]), "--frames", str(int(rng.integers(2, 9))),
+           "--bounces", str([0, 1, 2, 4, 8, 16, 32][int(rng.integers(0, 7))]), "--frames", str(int(rng.integers(2, 9))),
            "--fov", str([120, 90][int(rng.integers(0, 2))]), "--skip-seeds", str(int(rng.integers(0, 500))),
            "--camera=" + ",".join("%.4f" % v for v in list(pos) + list(facing))]
     run = subprocess.run(cmd, capture_output=True, text=True)
