@@ -78,6 +78,15 @@ void rth_rand_seed_triples(uint32_t nFrames, float *out3);
 /* Object paths a RayTracer.ini names, newline separated, into buf; returns their number or -1.
  * skyboxDir (may be NULL) receives [SkyBox] Path. */
 int rth_ini_object_paths(const char *iniPath, char *buf, uint32_t bufSize, char *skyboxDir, uint32_t skyboxDirSize);
+/* The values a RayTracer.ini holds under [section] name, as the reference's ConfigParser::aConfigVec<std::string>
+ * returns them (src/ConfigParser/ConfigParser.cpp:31-86, Include/ConfigParser/ConfigParser.hpp:68-87): each value
+ * followed by '\n' in buf; returns their number (0 for a key the file does not define), or -1 when the file does not
+ * parse, with the reference's message ("<path>:<line>: parsing error \n<line>") in errBuf (may be NULL). */
+int rth_ini_values(const char *iniPath, const char *section, const char *name, char *buf, uint32_t bufSize, char *errBuf, uint32_t errSize);
+/* One value converted like ConfigParser::aConfig<T> (ConfigParser.hpp:52-66, ConfigParser.cpp:88-108): kind 0 = int,
+ * 1 = float, 2 = bool; stream extraction, hexadecimal when the text contains "0x". A missing key or position gives 0
+ * (the reference indexes without a check there). */
+int rth_ini_number(const char *iniPath, const char *section, const char *name, uint32_t pos, int kind, double *out);
 int rth_write_png_rgb8(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb, int flipVertically);
 /* PNG decode as the reference's stbi_load(path, .., channels) (src/main.cpp:64,96): 8-bit pixels, rows in file
  * order, converted to 3 or 4 channels. Call with pixels == NULL to get the size. Returns 0 or RT_ERR_INVALID. */

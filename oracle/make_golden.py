@@ -22,6 +22,10 @@ What is recorded (inputs AND the reference's outputs, as data):
                  own BvhTree (compiled from its sources into oracle/_ref/libref_host.so)
   loader_*.npz   object files written by us in the reference's formats (tests/golden/objects/), and
                  what the reference's ObjectLoader/OFFLoader + BvhTree make of them
+  ini_reference.npz  ini files written by us (tests/golden/ini/) and what the reference's own ConfigParser (compiled from
+                 its sources) returns for them: value lists per key, typed values, exception messages
+  post_*.npz     accumulation images in, the reference's bloom chain (its three post shaders and two blits, run on
+                 llvmpipe in main.cpp's order) out; post_real.npz replays the reference's whole frame loop on a scene
 Every file stores a manifest string (Mesa version, flags).
 """
 import ctypes
@@ -397,23 +401,18 @@ def loader_fixtures(ref):
     np.savez_compressed(os.path.join(GOLD, "loader_reference.npz"), **out)
 
 
-def boundary_safe_hdr(W, H, seed):
-    """HDR test image that is constant on 5x5 blocks offset by 2 pixels. The reference's NEAREST
-    down-blits sample exactly on texel boundaries for the even factors (10, 20, 40): which of the two
-    neighbouring texels llvmpipe then takes is rounding noise of its interpolator. On this image both
-    candidates always carry the same value, so the whole chain is comparable."""
+def noisy_hdr(W, H, seed):
+    """HDR test image without any structure the blits could hide behind: bright discs on a dim background, every
+    texel scaled by its own random factor, so that reading a neighbouring texel changes the result everywhere."""
     r = np.random.default_rng(seed)
-    bw, bh = (W + 3) // 5 + 1, (H + 3) // 5 + 1
-    base = (r.random((bh, bw, 3)) * 0.9).astype(f32)
-    yy, xx = np.mgrid[0:bh, 0:bw]
-    for _ in range(10):
-        cx, cy = r.integers(0, bw), r.integers(0, bh)
-        rad = r.integers(1, max(2, bw // 8))
-        base[((xx - cx) ** 2 + (yy - cy) ** 2) <= rad * rad] = r.uniform(1.2, 8.0, 3).astype(f32)
-    base[0, :4] = (0.0, 2.0, 0.0)            # a bright texel with zero channels: the 0/0 centre tap
-    yy, xx = np.mgrid[0:H, 0:W]
     img = np.zeros((H, W, 4), f32)
-    img[..., :3] = base[(yy + 3) // 5, (xx + 3) // 5]
+    img[..., :3] = (r.random((H, W, 3)) * 0.8).astype(f32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(10):
+        cx, cy, rad = r.integers(0, W), r.integers(0, H), r.integers(2, max(3, W // 8))
+        img[((xx - cx) ** 2 + (yy - cy) ** 2) < rad * rad, :3] = r.uniform(1.0, 9.0, 3).astype(f32)
+    img[..., :3] *= (0.5 + r.random((H, W, 3))).astype(f32)
+    img[0, :4, :3] = (0.0, 2.0, 0.0)         # bright texels with zero channels: the 0/0 centre tap
     return img
 
 
@@ -422,7 +421,7 @@ def post_fixture(gl):
     ref = ReferenceRenderer(W, H, gl=gl)
     out = {"width": W, "height": H, "manifest": manifest(gl)}
     for frame in range(3):                   # consecutive frames: the tmp texture carries over
-        a = boundary_safe_hdr(W, H, 40 + frame)
+        a = noisy_hdr(W, H, 40 + frame)
         ref.write_accum(a)
         rgba, rgb8 = ref.postprocess(True)
         out["accum%d" % frame] = a
@@ -435,6 +434,122 @@ def post_fixture(gl):
     print("post_reference: 3 frames %dx%d" % (W, H))
 
 
+def post_real_fixture(gl, tmp):
+    """The reference's frame loop on a real scene: tracer draw, then the bloom chain, every frame (main.cpp:224-279).
+    Recorded for the last three of 16 frames of the light box (its lamp is far above the 1.5 bloom threshold): the
+    accumulation image each chain run started from and what the chain made of it. The chain's tmp texture carries
+    pixels from frame to frame, so a test replays all 16 frames from the scene arrays stored with the images."""
+    W, H, frames = 250, 130, 16
+    sc = scene_from(scenes.lightbox(), tmp + "/post_real")
+    noise, sky, seeds = scenes.noise_texture(64, 48, seed=7), scenes.sky_cubemap(32, seed=3), scenes.frame_seeds(frames)
+    ref = ReferenceRenderer(W, H, gl=gl)
+    ref.set_scene(sc.tri12, sc.matidx, sc.node8)
+    ref.set_materials(sc.materials)
+    ref.set_camera(**DEFAULT_CAMERA)
+    ref.set_noise(noise)
+    ref.set_skybox(sky)
+    ref.set_bounce_limit(4)
+    ref.clear()
+    out = dict(width=W, height=H, frames=frames, first_kept_frame=frames - 3, manifest=manifest(gl), bounce_limit=4,
+               tri12=sc.tri12, matidx=sc.matidx, node8=sc.node8, materials=sc.materials, noise=noise, sky=sky, seeds=seeds,
+               cam_position=np.asarray(DEFAULT_CAMERA["position"], f32), cam_facing=np.asarray(DEFAULT_CAMERA["facing"], f32),
+               cam_fov=f32(DEFAULT_CAMERA["fov"]), cam_vpw=f32(DEFAULT_CAMERA["viewport_width"]))
+    for k in range(frames):
+        ref.render(k, seeds[k:k + 1])
+        rgba, rgb8 = ref.postprocess(True)
+        j = k - (frames - 3)
+        if j >= 0:
+            out["accum%d" % j] = ref.read_accum()
+            out["final%d" % j] = rgba[..., :3].copy()
+            out["rgb8_%d" % j] = rgb8
+    bright = int((np.linalg.norm(out["accum2"][..., :3], axis=-1) >= 1.5).sum())
+    assert bright > 50, "the fixture must contain pixels above the bloom threshold"
+    np.savez_compressed(os.path.join(GOLD, "post_real.npz"), **out)
+    print("post_real: lightbox %dx%d, frames %d..%d, %d pixels above the bloom threshold" % (W, H, frames - 3, frames - 1, bright))
+
+
+INI_CASES = {
+    # name: (file bytes, [(section, key)] string queries, [(section, key, pos, kind)] typed queries)
+    "shipped_layout": (b"[ShaderPaths]\nTracerVert = ./src/shaders/Vertex.glsl\nTracerFrag = ./src/shaders/Fragment.glsl\n\n[SkyBox]\n"
+                       b"Path = ./Textures/DaylightBox\n\n[Objects]\nDirectoryPath = ./Objects\n"
+                       b"Filenames = LightBox.txt, LightBox2.txt,LightBox3.txt ,Teapot.txt\n",
+                       [("ShaderPaths", "TracerVert"), ("ShaderPaths", "TracerFrag"), ("SkyBox", "Path"), ("Objects", "DirectoryPath"),
+                        ("Objects", "Filenames"), ("Objects", "Missing"), ("Nowhere", "Path")], []),
+    "white_space": (b"  [ Sky Box ]  \n\tPath\t=\t./Textures/Day light Box \n  Spaced Key = a b , c\td ,  e \n",
+                    [("SkyBox", "Path"), ("SkyBox", "SpacedKey"), ("Sky Box", "Path")], []),
+    "comments": (b"; leading comment\n   ; indented comment\n[A]\nk = v ; not a comment\n;k2 = hidden\nk3 = ;x\n; [B]\nk4 = 1\n",
+                 [("A", "k"), ("A", "k2"), ("A", "k3"), ("A", "k4"), ("B", "k4")], []),
+    "duplicates": (b"[A]\nk = first, 1\nk = second\n[B]\nk = other\n[A]\nk = third\nj = late\n",
+                   [("A", "k"), ("B", "k"), ("A", "j")], []),
+    "empty_values": (b"[A]\nnone =\ntrail = a,\nlead = ,b\ndouble = a,,b\nonly = ,\nmany = ,,,\n",
+                     [("A", "none"), ("A", "trail"), ("A", "lead"), ("A", "double"), ("A", "only"), ("A", "many")], []),
+    "no_equals": (b"[A]\nfine = 1\n\n[B]\nalso = 2\nthis line has no equals sign\nnever = 3\n", [("A", "fine")], []),
+    "no_equals_first": (b"oops\n", [], []),
+    "section_with_tail": (b"[A] ; tail\nk = 1\n", [], []),
+    "no_section": (b"k = top\n[A]\nk = inner\n[]\nk = empty section\n", [("", "k"), ("A", "k")], []),
+    "numbers": (b"[N]\ni = 42, -7, 0x1f, 12abc, abc\nf = 1.5, -2.25e2, .5, 3\nb = true, TRUE, 1, false, FALSE, 0, yes, True\n",
+                [("N", "i"), ("N", "f"), ("N", "b")],
+                [("N", "i", 0, "int"), ("N", "i", 1, "int"), ("N", "i", 2, "int"), ("N", "i", 3, "int"), ("N", "i", 4, "int"),
+                 ("N", "f", 0, "float"), ("N", "f", 1, "float"), ("N", "f", 2, "float"), ("N", "f", 3, "float"), ("N", "i", 0, "float"),
+                 ("N", "b", 0, "bool"), ("N", "b", 1, "bool"), ("N", "b", 2, "bool"), ("N", "b", 3, "bool"), ("N", "b", 4, "bool"),
+                 ("N", "b", 5, "bool"), ("N", "b", 6, "bool"), ("N", "b", 7, "bool")]),
+    "odd_lines": (b"[x=1\n[A]\nk = a=b=c\n=novalue\nj]=2\n[B = 3\n", [("", "[x"), ("A", "k"), ("A", ""), ("A", "j]"), ("A", "[B")], []),
+    "crlf_tabs_utf8": ("[A]\r\nPath\t= ./Textures/Té ü\r\n\r\n;c\r\nk = 1 ,\t2\r\n".encode("utf-8"), [("A", "Path"), ("A", "k")], []),
+    "empty_file": (b"", [("A", "k")], []),
+}
+
+
+def ini_fixture():
+    """ini files written here (tests/golden/ini/) and what the reference's own ConfigParser, compiled from its sources
+    (oracle/_ref/libref_config.so), answers for them: value lists, typed values, or the message of the exception."""
+    import json
+    L = ctypes.CDLL(os.path.join(HERE, "_ref", "libref_config.so"))
+    L.ref_ini_open.restype = ctypes.c_void_p
+    L.ref_ini_open.argtypes = [ctypes.c_char_p]
+    L.ref_ini_close.argtypes = [ctypes.c_void_p]
+    L.ref_ini_error.restype = ctypes.c_char_p
+    L.ref_ini_error.argtypes = [ctypes.c_void_p]
+    L.ref_ini_values.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+    L.ref_ini_text.restype = ctypes.c_char_p
+    L.ref_ini_text.argtypes = [ctypes.c_void_p]
+    for fn, rt in (("ref_ini_int", ctypes.c_int32), ("ref_ini_float", ctypes.c_float), ("ref_ini_bool", ctypes.c_int32)):
+        getattr(L, fn).restype = rt
+        getattr(L, fn).argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_uint32]
+    d = os.path.join(GOLD, "ini")
+    os.makedirs(d, exist_ok=True)
+    cases = {}
+    cwd = os.getcwd()
+    os.chdir(GOLD)                 # error messages quote the path as given: keep it relative
+    try:
+        for name, (text, queries, typed) in INI_CASES.items():
+            rel = "ini/%s.ini" % name
+            with open(rel, "wb") as f:
+                f.write(text)
+            h = L.ref_ini_open(rel.encode())
+            err = L.ref_ini_error(h).decode("utf-8")
+            case = {"path": rel, "error": err, "values": [], "typed": []}
+            if not err:
+                for sec, key in queries:
+                    n = L.ref_ini_values(h, sec.encode(), key.encode())
+                    vals = L.ref_ini_text(h).decode("utf-8").split("\n")[:n]
+                    case["values"].append([sec, key, vals])
+                for sec, key, pos, kind in typed:
+                    v = {"int": L.ref_ini_int, "float": L.ref_ini_float, "bool": L.ref_ini_bool}[kind](h, sec.encode(), key.encode(), pos)
+                    case["typed"].append([sec, key, pos, kind, float(v)])
+            L.ref_ini_close(h)
+            cases[name] = case
+        h = L.ref_ini_open(b"ini/does_not_exist.ini")      # an unreadable file is an empty configuration, not an error
+        cases["missing_file"] = {"path": "ini/does_not_exist.ini", "error": L.ref_ini_error(h).decode(),
+                                 "values": [["A", "k", L.ref_ini_text(h).decode().split("\n")[:L.ref_ini_values(h, b"A", b"k")]]], "typed": []}
+        L.ref_ini_close(h)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(GOLD, "ini_reference.npz"), cases_json=np.array(json.dumps(cases, indent=1)),
+                        manifest=np.array("reference src/ConfigParser/ConfigParser.cpp + Include/ConfigParser/ConfigParser.hpp compiled with g++ -O3; "
+                                          "ini files written by oracle/make_golden.py; paths relative to tests/golden"))
+    print("ini_reference: %d files, %d with a parsing error" % (len(cases), sum(1 for c in cases.values() if c["error"])))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     import tempfile
@@ -445,6 +560,13 @@ def main():
         return
     if "--only-triangle-edges" in sys.argv:
         triangle_edge_fixture(gl)
+        return
+    if "--only-ini" in sys.argv:
+        ini_fixture()
+        return
+    if "--only-post" in sys.argv:
+        post_fixture(gl)
+        post_real_fixture(gl, tmp)
         return
     noise = scenes.noise_texture(64, 48, seed=7)
     sky = scenes.sky_cubemap(32, seed=3)
@@ -465,9 +587,11 @@ def main():
     sky_rotation_fixture(gl)
     triangle_edge_fixture(gl)
     post_fixture(gl)
+    post_real_fixture(gl, tmp)
     ref = RefHost()
     bvh_fixtures(ref)
     loader_fixtures(ref)
+    ini_fixture()
 
 
 if __name__ == "__main__":

@@ -94,14 +94,79 @@ void bloom_pass(const Img& level, Img& out) {
         }
 }
 
+// ---- glBlitFramebuffer as Mesa 23.2.1 llvmpipe executes it ------------------------------------------------
+// The reference leaves its blits (main.cpp:244-248 NEAREST, :261-265 LINEAR) to the GL implementation; its parity
+// target is llvmpipe, where a blit is a textured quad: src/gallium/auxiliary/util/u_blitter.c draws the destination
+// rectangle as a fan of two triangles with normalised texture coordinates, the draw module maps the vertices to the
+// window with one fused multiply-add, lp_state_setup.c fits a plane a0 + dadx*x + dady*y through each triangle's
+// texture coordinates, lp_bld_interp.c evaluates it per pixel with two fused multiply-adds, and lp_bld_sample_soa.c
+// turns the coordinate into texels. The sample points of the even down-blit factors lie exactly on texel boundaries,
+// so the last bit of that arithmetic decides which texel is read (for factor 20 at 1280x720: 20x+9, not 20x+10).
+// Mesa is not part of the reference tree (system library, 23.2.1-1ubuntu3.1~22.04.3); the steps below restate its
+// arithmetic and are pinned by measurement: oracle/glsl_ref/probe_blit.py blits index ramps and random images
+// through llvmpipe and finds every texel choice and every filtered value reproduced exactly.
+struct Plane { float a0, dadx, dady; };
+struct BlitPlan {
+    Plane s[2], t[2];        // per triangle of the fan: [0] holds the destination's (x2, y1) corner, [1] its (x1, y2) corner
+    long long dw, dh;        // destination rectangle [0,dw) x [0,dh): its diagonal separates the two triangles
+    float texW, texH;        // size of the source texture
+};
+
+// u_blitter.c blitter_set_rectangle (pixel -> clip space) followed by the viewport transform of the draw module.
+inline float window_coord(int x, int surfaceSize) {
+    const float ndc = (float)x / (float)surfaceSize * 2.0f - 1.0f;
+    const float half = 0.5f * (float)surfaceSize;
+    return fmaf(ndc, half, half);
+}
+
+// lp_state_setup.c: the plane through attribute values a0v, a1v, a2v at window positions p0, p1, p2.
+inline Plane fit_plane(const float p0[2], const float p1[2], const float p2[2], float a0v, float a1v, float a2v) {
+    const float x0c = p0[0] - 0.5f, y0c = p0[1] - 0.5f;
+    const float dx01 = p0[0] - p1[0], dy01 = p0[1] - p1[1], dx20 = p2[0] - p0[0], dy20 = p2[1] - p0[1];
+    const float ooa = 1.0f / (dx01 * dy20 - dy01 * dx20);
+    const float dy20o = dy20 * ooa, dy01o = dy01 * ooa, dx20o = dx20 * ooa, dx01o = dx01 * ooa;
+    const float da01 = a0v - a1v, da20 = a2v - a0v;
+    Plane pl;
+    pl.dadx = da01 * dy20o - da20 * dy01o;
+    pl.dady = da20 * dx01o - da01 * dx20o;
+    pl.a0 = a0v - (pl.dadx * x0c + pl.dady * y0c);
+    return pl;
+}
+
+// A blit of the source rectangle [0,sw) x [0,sh) of a texW x texH texture onto [0,dw) x [0,dh) of a surfW x surfH surface.
+BlitPlan plan_blit(int sw, int sh, int texW, int texH, int dw, int dh, int surfW, int surfH) {
+    const float x1 = window_coord(0, surfW), x2 = window_coord(dw, surfW), y1 = window_coord(0, surfH), y2 = window_coord(dh, surfH);
+    const float s2 = (float)sw / (float)texW, t2 = (float)sh / (float)texH;
+    const float v0[2] = {x1, y1}, v1[2] = {x2, y1}, v2[2] = {x2, y2}, v3[2] = {x1, y2};
+    BlitPlan b;
+    // the fan's triangles (v0,v1,v2) and (v0,v2,v3) reach the setup code with their first two vertices exchanged
+    b.s[0] = fit_plane(v1, v0, v2, s2, 0.0f, s2);
+    b.t[0] = fit_plane(v1, v0, v2, 0.0f, 0.0f, t2);
+    b.s[1] = fit_plane(v2, v0, v3, s2, 0.0f, 0.0f);
+    b.t[1] = fit_plane(v2, v0, v3, t2, 0.0f, t2);
+    b.dw = dw; b.dh = dh; b.texW = (float)texW; b.texH = (float)texH;
+    return b;
+}
+
+// Texture coordinates of destination pixel (x, y), scaled to texels (lp_bld_interp.c, then the sampler's multiply).
+inline void blit_coords(const BlitPlan& b, int x, int y, float& u, float& v) {
+    // pixel centres on the shared diagonal belong to the first triangle
+    const int tri = ((2LL * x + 1) * b.dh - (2LL * y + 1) * b.dw >= 0) ? 0 : 1;
+    const float fx = (float)x, fy = (float)y;
+    u = fmaf(b.s[tri].dady, fy, fmaf(b.s[tri].dadx, fx, b.s[tri].a0)) * b.texW;
+    v = fmaf(b.t[tri].dady, fy, fmaf(b.t[tri].dadx, fx, b.t[tri].a0)) * b.texH;
+}
+
 // glBlitFramebuffer(GL_NEAREST) of the whole source onto the corner [0,w) x [0,h).
 void blit_down_nearest(const float* accumRGBA, int W, int H, Img& dst, int w, int h) {
+    const BlitPlan b = plan_blit(W, H, W, H, w, h, dst.W, dst.H);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
-            int sx = (int)floorf(((float)x + 0.5f) * ((float)W / (float)w));
-            int sy = (int)floorf(((float)y + 0.5f) * ((float)H / (float)h));
-            if (sx > W - 1) sx = W - 1;
-            if (sy > H - 1) sy = H - 1;
+            float u, v;
+            blit_coords(b, x, y, u, v);
+            int sx = (int)u, sy = (int)v;                       // truncation, then clamp to the texture
+            sx = sx < 0 ? 0 : (sx > W - 1 ? W - 1 : sx);
+            sy = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy);
             const float* s = accumRGBA + ((size_t)sy * W + sx) * 4;
             float* d = dst.at(x, y);
             d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
@@ -112,21 +177,23 @@ void blit_down_nearest(const float* accumRGBA, int W, int H, Img& dst, int w, in
 // bilinear on the whole source texture (CLAMP_TO_EDGE), so texels just outside the corner bleed in.
 void blit_up_linear(const Img& src, int w, int h, Img& dst) {
     const int W = dst.W, H = dst.H;
+    const BlitPlan b = plan_blit(w, h, src.W, src.H, W, H, W, H);
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
-            float u = ((float)x + 0.5f) * ((float)w / (float)W) - 0.5f;
-            float v = ((float)y + 0.5f) * ((float)h / (float)H) - 0.5f;
-            float fu = floorf(u), fv = floorf(v);
-            float wx = u - fu, wy = v - fv;
-            int x0 = (int)fu, y0 = (int)fv, x1 = x0 + 1, y1 = y0 + 1;
-            auto cl = [](int a, int n) { return a < 0 ? 0 : (a > n - 1 ? n - 1 : a); };
-            x0 = cl(x0, src.W); x1 = cl(x1, src.W); y0 = cl(y0, src.H); y1 = cl(y1, src.H);
-            const float *a = src.at(x0, y0), *b = src.at(x1, y0), *c = src.at(x0, y1), *d = src.at(x1, y1);
+            float u, v;
+            blit_coords(b, x, y, u, v);
+            u = fmaxf(fminf(u, b.texW) - 0.5f, 0.0f);
+            v = fmaxf(fminf(v, b.texH) - 0.5f, 0.0f);
+            const float fu = floorf(u), fv = floorf(v);
+            const float wx = u - fu, wy = v - fv;
+            const int x0 = (int)fu, y0 = (int)fv;
+            const int x1 = x0 + 1 > src.W - 1 ? src.W - 1 : x0 + 1, y1 = y0 + 1 > src.H - 1 ? src.H - 1 : y0 + 1;
+            const float *a = src.at(x0, y0), *bb = src.at(x1, y0), *c = src.at(x0, y1), *d = src.at(x1, y1);
             float* o = dst.at(x, y);
             for (int k = 0; k < 3; ++k) {
-                float top = a[k] + wx * (b[k] - a[k]);
-                float bot = c[k] + wx * (d[k] - c[k]);
-                o[k] = top + wy * (bot - top);
+                const float top = fmaf(wx, bb[k] - a[k], a[k]);
+                const float bot = fmaf(wx, d[k] - c[k], c[k]);
+                o[k] = fmaf(wy, bot - top, top);
             }
         }
 }

@@ -110,6 +110,8 @@ SIGNATURES = {
     "rth_bounce_limit_from_key": (I, [I]),
     "rth_rand_seed_triples": (None, [U32, P]),
     "rth_ini_object_paths": (I, [ctypes.c_char_p, ctypes.c_char_p, U32, ctypes.c_char_p, U32]),
+    "rth_ini_values": (I, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, U32, ctypes.c_char_p, U32]),
+    "rth_ini_number": (I, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, U32, I, ctypes.POINTER(ctypes.c_double)]),
     "rth_write_png_rgb8": (I, [ctypes.c_char_p, U32, U32, P, I]),
     "rth_read_png": (I, [ctypes.c_char_p, I, ctypes.POINTER(U32), ctypes.POINTER(U32), P, ctypes.c_uint64]),
     "rth_app_create": (I, [P, U32, U32, ctypes.POINTER(P)]),

@@ -59,6 +59,24 @@ def ini_object_paths(path):
     return (text.split("\n") if n else []), sky.value.decode()
 
 
+def ini_values(path, section, name):
+    """Values under [section] name as the reference's aConfigVec<std::string> returns them; ValueError (carrying the
+    reference's message) when the file does not parse."""
+    buf, err = ctypes.create_string_buffer(1 << 16), ctypes.create_string_buffer(4096)
+    n = _lib.lib().rth_ini_values(path.encode(), section.encode(), name.encode(), buf, len(buf), err, len(err))
+    if n < 0:
+        raise ValueError(err.value.decode())
+    return buf.value.decode().split("\n")[:n]
+
+
+def ini_number(path, section, name, pos=0, kind=int):
+    out = ctypes.c_double()
+    rc = _lib.lib().rth_ini_number(path.encode(), section.encode(), name.encode(), pos, {int: 0, float: 1, bool: 2}[kind], ctypes.byref(out))
+    if rc != 0:
+        raise ValueError("cannot read %s / %s from %s" % (section, name, path))
+    return kind(out.value)
+
+
 def write_png(path, rgb, flip=False):
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     rc = _lib.lib().rth_write_png_rgb8(path.encode(), rgb.shape[1], rgb.shape[0], rgb.ctypes.data, int(flip))

@@ -12,8 +12,9 @@
 //     blur   49-tap disc, B:20-46, LDS-tiled: a 40x16 texel tile feeds 32x8 outputs
 //     up     levels[i] <- bilinear up-blit of tmp[0:w,0:h]                    main.cpp:261-265
 //   final  tmp <- pow(accum, 1/1.61803) + levels[0..3]                        Fi:17-30
-// Nearest down-blit: the sample point of an even factor lies exactly on a texel boundary; the
-// texel at floor((x + 0.5) * W / w) is taken.
+// The two blits are evaluated as Mesa llvmpipe (the reference's parity target) evaluates glBlitFramebuffer: see
+// BlitMap below. That matters for the down-blit: the sample point of an even factor lies exactly on a texel
+// boundary, and the rounding of the interpolated coordinate decides which of the two texels is read.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -38,13 +39,37 @@ struct AccumView {
     }
 };
 
+// ---- glBlitFramebuffer (main.cpp:244-248, 261-265) with llvmpipe's arithmetic ----
+// llvmpipe draws a blit as two triangles that share the diagonal of the destination rectangle and carry normalised
+// texture coordinates. Per triangle and coordinate it fits a plane c0 + cx * x + cy * y in fp32 (its coefficients are
+// off by an ulp or so, differently for the two triangles), evaluates the plane at the pixel's integer position with
+// two fused multiply-adds, and multiplies by the texture size. The planes are fitted on the host (MakeBlitMap); the
+// kernels repeat the per-pixel part operation by operation, so that NEAREST reads the texel llvmpipe reads (with a
+// down-blit factor of 20 at 1280 x 720 that is texel 20x + 9 in every column, never the 20x + 10 of exact arithmetic)
+// and LINEAR gets its weights bit for bit.
+struct BlitPlane { float c0, cx, cy; };
+struct BlitMap {
+    BlitPlane u[2], v[2];     // horizontal / vertical coordinate; [0]: triangle below the diagonal, [1]: above it
+    int dw, dh;               // destination rectangle [0,dw) x [0,dh)
+    float texW, texH;         // source texture size in texels
+};
+
+__device__ __forceinline__ void blit_source_coords(const BlitMap& m, int x, int y, float& su, float& sv) {
+    // which side of the diagonal from (0,0) to (dw,dh) the pixel centre lies on; centres on it go to triangle 0
+    const bool below = (long long)(2 * x + 1) * m.dh >= (long long)(2 * y + 1) * m.dw;
+    const BlitPlane pu = below ? m.u[0] : m.u[1], pv = below ? m.v[0] : m.v[1];
+    const float fx = (float)x, fy = (float)y;
+    su = __fmaf_rn(pu.cy, fy, __fmaf_rn(pu.cx, fx, pu.c0)) * m.texW;
+    sv = __fmaf_rn(pv.cy, fy, __fmaf_rn(pv.cx, fx, pv.c0)) * m.texH;
+}
+
 // (S = row stride of tmp and pre, in texels: the window width when they are whole-window images)
-__global__ void down_kernel(AccumView accum, float4* __restrict__ tmp, int S, int W, int H, int w, int h) {
+__global__ void down_kernel(AccumView accum, float4* __restrict__ tmp, int S, int W, int H, int w, int h, BlitMap map) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
-    int sx = (int)floorf(((float)x + 0.5f) * ((float)W / (float)w));
-    int sy = (int)floorf(((float)y + 0.5f) * ((float)H / (float)h));
-    sx = min(sx, W - 1); sy = min(sy, H - 1);
+    float su, sv;
+    blit_source_coords(map, x, y, su, sv);
+    const int sx = min(max((int)su, 0), W - 1), sy = min(max((int)sv, 0), H - 1);      // truncate, clamp to the texture
     float4 s = accum.at(sx, sy);
     tmp[(size_t)y * S + x] = make_float4(s.x, s.y, s.z, 0.0f);
 }
@@ -118,22 +143,25 @@ __global__ void snap_kernel(const float4* __restrict__ tmp, float4* __restrict__
     snap[(size_t)y * sw + x] = tmp[(size_t)y * S + x];
 }
 
-struct LevelView { const float4* snap; int w, h, sw, sh; };
+struct LevelView { const float4* snap; int w, h, sw, sh; BlitMap map; int texW, texH; };
 
 // One pixel of the GL_LINEAR up-blit of a level's corner [0:w, 0:h] to the whole image, read from its snapshot.
-__device__ __forceinline__ float4 up_sample(const LevelView& L, int x, int y, int W, int H) {
-    float u = ((float)x + 0.5f) * ((float)L.w / (float)W) - 0.5f;
-    float v = ((float)y + 0.5f) * ((float)L.h / (float)H) - 0.5f;
-    float fu = floorf(u), fv = floorf(v);
-    float wx = u - fu, wy = v - fv;
-    int x0 = (int)fu, y0 = (int)fv, x1 = x0 + 1, y1 = y0 + 1;
-    // x1 <= w and y1 <= h always hold, so clamping to the snapshot equals clamping to the texture
-    x0 = min(max(x0, 0), L.sw - 1); x1 = min(max(x1, 0), L.sw - 1); y0 = min(max(y0, 0), L.sh - 1); y1 = min(max(y1, 0), L.sh - 1);
+__device__ __forceinline__ float4 up_sample(const LevelView& L, int x, int y) {
+    float u, v;
+    blit_source_coords(L.map, x, y, u, v);
+    // CLAMP_TO_EDGE bilinear footprint: texel centres at +0.5, coordinate held inside the texture
+    u = fmaxf(fminf(u, L.map.texW) - 0.5f, 0.0f);
+    v = fmaxf(fminf(v, L.map.texH) - 0.5f, 0.0f);
+    const float fu = floorf(u), fv = floorf(v);
+    const float wx = u - fu, wy = v - fv;
+    int x0 = (int)fu, y0 = (int)fv, x1 = min(x0 + 1, L.texW - 1), y1 = min(y0 + 1, L.texH - 1);
+    // the footprint never leaves [0, w] x [0, h], which is what the snapshot holds (or the whole texture, if smaller)
+    x0 = min(x0, L.sw - 1); x1 = min(x1, L.sw - 1); y0 = min(y0, L.sh - 1); y1 = min(y1, L.sh - 1);
     float4 a = L.snap[(size_t)y0 * L.sw + x0], b = L.snap[(size_t)y0 * L.sw + x1], c = L.snap[(size_t)y1 * L.sw + x0], d = L.snap[(size_t)y1 * L.sw + x1];
-    float4 o;
-    { float top = a.x + wx * (b.x - a.x), bot = c.x + wx * (d.x - c.x); o.x = top + wy * (bot - top); }
-    { float top = a.y + wx * (b.y - a.y), bot = c.y + wx * (d.y - c.y); o.y = top + wy * (bot - top); }
-    { float top = a.z + wx * (b.z - a.z), bot = c.z + wx * (d.z - c.z); o.z = top + wy * (bot - top); }
+    float4 o;      // llvmpipe's lerps are fused: v0 + w * (v1 - v0) rounded once
+    { float top = __fmaf_rn(wx, b.x - a.x, a.x), bot = __fmaf_rn(wx, d.x - c.x, c.x); o.x = __fmaf_rn(wy, bot - top, top); }
+    { float top = __fmaf_rn(wx, b.y - a.y, a.y), bot = __fmaf_rn(wx, d.y - c.y, c.y); o.y = __fmaf_rn(wy, bot - top, top); }
+    { float top = __fmaf_rn(wx, b.z - a.z, a.z), bot = __fmaf_rn(wx, d.z - c.z, c.z); o.z = __fmaf_rn(wy, bot - top, top); }
     o.w = 0.0f;
     return o;
 }
@@ -165,7 +193,7 @@ __global__ void final_kernel(AccumView accum, LevelView l0, LevelView l1, LevelV
     const size_t i = (size_t)y * W + x;
     float4 s = accum.at(x, y);
     const float g = 1.0f / 1.61803f;
-    float4 a = up_sample(l0, x, y, W, H), b = up_sample(l1, x, y, W, H), c = up_sample(l2, x, y, W, H), d = up_sample(l3, x, y, W, H);
+    float4 a = up_sample(l0, x, y), b = up_sample(l1, x, y), c = up_sample(l2, x, y), d = up_sample(l3, x, y);
     float r = gamma_pow(s.x, g), gr = gamma_pow(s.y, g), bl = gamma_pow(s.z, g);
     r += a.x; r += b.x; r += c.x; r += d.x;
     gr += a.y; gr += b.y; gr += c.y; gr += d.y;
@@ -196,6 +224,39 @@ void Release(PostScratch* s) {
     for (auto& l : s->snap) if (l) (void)hipFree(l);
     if (s->rgb8) (void)hipFree(s->rgb8);
     *s = PostScratch();
+}
+
+// The planes of a blit from the source rectangle [0,sw) x [0,sh) of a texW x texH texture onto [0,dw) x [0,dh) of a
+// surfW x surfH render target, fitted the way llvmpipe's triangle setup fits them (fp32 throughout, one fused
+// multiply-add where the vertices are mapped to the window, none in the fit itself).
+BlitPlane FitPlane(float ax, float ay, float bx, float by, float cx, float cy, float va, float vb, float vc) {
+    // vertices a, b, c with attribute values va, vb, vc; a is the vertex the constant term is anchored at
+    const float abx = ax - bx, aby = ay - by, cax = cx - ax, cay = cy - ay;
+    const float rArea = 1.0f / (abx * cay - aby * cax);
+    const float cayN = cay * rArea, abyN = aby * rArea, caxN = cax * rArea, abxN = abx * rArea;
+    const float dab = va - vb, dca = vc - va;
+    BlitPlane p;
+    p.cx = dab * cayN - dca * abyN;
+    p.cy = dca * abxN - dab * caxN;
+    p.c0 = va - (p.cx * (ax - 0.5f) + p.cy * (ay - 0.5f));
+    return p;
+}
+
+BlitMap MakeBlitMap(int sw, int sh, int texW, int texH, int dw, int dh, int surfW, int surfH) {
+    auto toWindow = [](int px, int size) {      // pixel -> clip space -> window, as the blit's vertices travel
+        const float clip = (float)px / (float)size * 2.0f - 1.0f, half = 0.5f * (float)size;
+        return fmaf(clip, half, half);
+    };
+    const float xl = toWindow(0, surfW), xr = toWindow(dw, surfW), yb = toWindow(0, surfH), yt = toWindow(dh, surfH);
+    const float uMax = (float)sw / (float)texW, vMax = (float)sh / (float)texH;
+    BlitMap m;
+    // triangle below the diagonal: corners (xr,yb), (xl,yb), (xr,yt) in the order the setup sees them; above: (xr,yt), (xl,yb), (xl,yt)
+    m.u[0] = FitPlane(xr, yb, xl, yb, xr, yt, uMax, 0.0f, uMax);
+    m.v[0] = FitPlane(xr, yb, xl, yb, xr, yt, 0.0f, 0.0f, vMax);
+    m.u[1] = FitPlane(xr, yt, xl, yb, xl, yt, uMax, 0.0f, 0.0f);
+    m.v[1] = FitPlane(xr, yt, xl, yb, xl, yt, vMax, 0.0f, vMax);
+    m.dw = dw; m.dh = dh; m.texW = (float)texW; m.texH = (float)texH;
+    return m;
 }
 
 // Region [0,R[i]) x [0,R'[i]) on which level i's blur output is needed:
@@ -239,12 +300,12 @@ void LaunchChain(hipStream_t st, const AccumView& view, int W, int H, const Chai
     LevelView lv[kLevels];
     for (int i = 0; i < kLevels; ++i) {
         const int w = W / ds[i], h = H / ds[i];
-        if (w > 0 && h > 0) hipLaunchKernelGGL(down_kernel, grid2(w, h), b2, 0, st, view, cb.tmp, S, W, H, w, h);
+        if (w > 0 && h > 0) hipLaunchKernelGGL(down_kernel, grid2(w, h), b2, 0, st, view, cb.tmp, S, W, H, w, h, MakeBlitMap(W, H, W, H, w, h, W, H));
         const int pw = min(W, rw[i] + kApron), ph = min(H, rh[i] + kApron);
         hipLaunchKernelGGL(pre_kernel, grid2(pw, ph), b2, 0, st, cb.tmp, cb.pre, S, pw, ph);
         hipLaunchKernelGGL(blur_kernel, grid2(rw[i], rh[i]), dim3(kBlurTX, kBlurTY), 0, st, cb.pre, cb.tmp, S, W, H, pw, ph, rw[i], rh[i]);
         hipLaunchKernelGGL(snap_kernel, grid2(cb.sw[i], cb.sh[i]), b2, 0, st, cb.tmp, cb.snap[i], S, cb.sw[i], cb.sh[i]);
-        lv[i] = LevelView{cb.snap[i], w, h, cb.sw[i], cb.sh[i]};
+        lv[i] = LevelView{cb.snap[i], w, h, cb.sw[i], cb.sh[i], MakeBlitMap(w, h, W, H, W, H, W, H), W, H};
     }
     hipLaunchKernelGGL(final_kernel, grid2(W, H), b2, 0, st, view, lv[0], lv[1], lv[2], lv[3], outRgba, outRgb8, W, H);
 }

@@ -133,6 +133,7 @@ int rth_scene_send(const rth_scene* s, rt_context* ctx) {
 #include <cstring>
 
 #include "app.h"
+#include "config_parser.h"
 #include "controls.h"
 #include "image_io.h"
 #include "video.h"
@@ -173,6 +174,37 @@ int rth_ini_object_paths(const char* iniPath, char* buf, uint32_t bufSize, char*
         return (int)paths.size();
     } catch (const std::exception&) {
         return -1;
+    }
+}
+int rth_ini_values(const char* iniPath, const char* section, const char* name, char* buf, uint32_t bufSize, char* errBuf, uint32_t errSize) {
+    if (!iniPath || !section || !name) return -1;
+    auto put = [](char* dst, uint32_t cap, const std::string& text) {
+        if (dst && cap) { std::strncpy(dst, text.c_str(), cap - 1); dst[cap - 1] = 0; }
+    };
+    try {
+        rta::ConfigParser ini(iniPath);
+        std::string joined;
+        const std::vector<std::string> values = ini.Values(section, name);
+        for (const std::string& v : values) { joined += v; joined += '\n'; }
+        put(buf, bufSize, joined);
+        put(errBuf, errSize, "");
+        return (int)values.size();
+    } catch (const std::exception& e) {
+        put(errBuf, errSize, e.what());
+        return -1;
+    }
+}
+int rth_ini_number(const char* iniPath, const char* section, const char* name, uint32_t pos, int kind, double* out) {
+    if (!iniPath || !section || !name || !out) return RT_ERR_INVALID;
+    try {
+        rta::ConfigParser ini(iniPath);
+        if (kind == 0) *out = (double)ini.Get<int>(section, name, pos);
+        else if (kind == 1) *out = (double)ini.Get<float>(section, name, pos);
+        else if (kind == 2) *out = ini.Get<bool>(section, name, pos) ? 1.0 : 0.0;
+        else return RT_ERR_INVALID;
+        return RT_OK;
+    } catch (const std::exception&) {
+        return RT_ERR_INVALID;
     }
 }
 int rth_write_png_rgb8(const char* path, uint32_t w, uint32_t h, const uint8_t* rgb, int flip) {

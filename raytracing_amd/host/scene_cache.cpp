@@ -250,8 +250,15 @@ bool ReadSceneBlob(const std::string& path, const uint8_t key[32], SceneData& s)
     BlobHeader h;
     std::memcpy(&h, b, sizeof h);
     if (h.magic != kMagic || h.version != kFormatVersion || std::memcmp(h.key, key, 32) != 0) return false;
-    const uint64_t need = sizeof h + (uint64_t)h.nTri * 52 + (uint64_t)h.nNode * 32 + (uint64_t)h.nMaterials * sizeof(Material) + h.warningBytes + 8;
-    if (need != file.size()) return false;
+    // Every count comes from the file: each term is bounded by the file's size before it is added, so that the sum
+    // cannot wrap around to the right value while a single term reaches far beyond the mapping.
+    const uint64_t size = file.size();
+    if (h.nTri >= (1u << 24) || h.warningBytes > size || (uint64_t)h.nMaterials * sizeof(Material) > size ||
+        (uint64_t)h.nNode * 32 > size || h.nWarnings > h.warningBytes) return false;
+    uint64_t need = sizeof h + 8;
+    if (__builtin_add_overflow(need, (uint64_t)h.nTri * 52, &need) || __builtin_add_overflow(need, (uint64_t)h.nNode * 32, &need) ||
+        __builtin_add_overflow(need, (uint64_t)h.nMaterials * sizeof(Material), &need) || __builtin_add_overflow(need, h.warningBytes, &need)) return false;
+    if (need != size) return false;
     uint64_t tail;
     std::memcpy(&tail, b + file.size() - 8, 8);
     if (tail != Checksum(b, file.size() - 8)) return false;

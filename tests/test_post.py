@@ -1,58 +1,100 @@
 """Bloom chain + final composite.
 
-CPU: the post oracle against llvmpipe output of the reference's three post shaders
-(tests/golden/post_reference.npz, three consecutive frames so that the carried-over tmp content
-is exercised). Tolerance 2e-5 absolute on float images (llvmpipe approximates pow(); everything
-else agrees to rounding), 8-bit read-back within one code.
-GPU: the HIP chain against the oracle, tolerance 2e-5 absolute (powf of two different libms)."""
+Fixtures (llvmpipe output of the reference's three post shaders and its two blits, three consecutive frames each so
+that the carried-over tmp content is exercised):
+  post_reference.npz  noisy synthetic HDR images: every texel differs from its neighbours, so a blit that reads a
+                      neighbouring texel shows everywhere
+  post_real.npz       the reference's own frame loop on the light box: tracer draw + bloom chain per frame, 16 frames,
+                      the last three recorded (accumulation image and what the chain made of it)
+The blits are reproduced exactly (texel choice of the NEAREST down-blit, weights of the LINEAR up-blit); what is left
+is pow(): llvmpipe evaluates it with polynomial approximations, the oracle with libm, the HIP chain with the hardware's
+exp2/log2. Tolerances, absolute, on float images with values up to about 12:
+  oracle vs llvmpipe  5e-6        HIP vs oracle  5e-6        HIP vs llvmpipe  8e-6
+8-bit read-back within one code."""
 import os
 
 import numpy as np
 import pytest
 
-from rt_oracle import PostOracle
-from util import GOLDEN
+from rt_oracle import Oracle, PostOracle
+from test_oracle_golden import load_into
+from util import GOLDEN, bits
 
 FX = np.load(os.path.join(GOLDEN, "post_reference.npz"))
+REAL = np.load(os.path.join(GOLDEN, "post_real.npz"))
 W, H = int(FX["width"]), int(FX["height"])
-TOL = 2e-5
+TOL_ORACLE_REF = 5e-6
+TOL_GPU_ORACLE = 5e-6
+TOL_GPU_REF = 8e-6
+
+
+def test_fixture_is_not_blit_safe():
+    """The texel the NEAREST down-blit must read differs from its neighbours (no structure hides a wrong choice)."""
+    a = FX["accum0"][..., :3]
+    assert (a[:, 1:] != a[:, :-1]).any(-1).mean() > 0.99
+    assert (a[1:] != a[:-1]).any(-1).mean() > 0.99
 
 
 def test_post_oracle_matches_reference_shaders():
     po = PostOracle(W, H)
     for f in range(3):
         rgba, rgb8 = po.run(FX["accum%d" % f])
-        assert np.abs(rgba[..., :3] - FX["final%d" % f]).max() <= TOL
+        assert np.abs(rgba[..., :3] - FX["final%d" % f]).max() <= TOL_ORACLE_REF
         assert np.abs(rgb8.astype(int) - FX["rgb8_%d" % f].astype(int)).max() <= 1
         assert (rgb8 != FX["rgb8_%d" % f]).any(-1).mean() < 0.002
     for i in range(4):
-        assert np.abs(po.level(i) - FX["level%d_2" % i]).max() <= TOL, i
+        assert np.abs(po.level(i) - FX["level%d_2" % i]).max() <= 1e-6, i
     assert FX["final2"].max() > 2.0      # the fixture does contain bloom
 
 
-def smooth_hdr(w, h, seed):
+def replay_real(renderer, post):
+    """The reference's frame loop on the post_real fixture: yields (kept index, accumulation, chain output, rgb8)."""
+    load_into(renderer, REAL)
+    renderer.set_bounce_limit(int(REAL["bounce_limit"]))
+    renderer.clear()
+    first = int(REAL["first_kept_frame"])
+    for k in range(int(REAL["frames"])):
+        renderer.render(k, REAL["seeds"][k:k + 1])
+        accum = renderer.read_accum()
+        rgba, rgb8 = post(accum)
+        if k >= first:
+            yield k - first, accum, rgba, rgb8
+
+
+def test_post_oracle_matches_reference_frame_loop():
+    w, h = int(REAL["width"]), int(REAL["height"])
+    assert (np.linalg.norm(REAL["accum2"][..., :3], axis=-1) >= 1.5).sum() > 50      # lamp pixels above the bloom threshold
+    o, po = Oracle(w, h), PostOracle(w, h)
+    for j, accum, rgba, rgb8 in replay_real(o, po.run):
+        assert (bits(accum[..., :3]) == bits(REAL["accum%d" % j][..., :3])).all()
+        assert np.abs(rgba[..., :3] - REAL["final%d" % j]).max() <= TOL_ORACLE_REF, j
+        assert np.abs(rgb8.astype(int) - REAL["rgb8_%d" % j].astype(int)).max() <= 1
+
+
+def noisy_hdr(w, h, seed):
     r = np.random.default_rng(seed)
     img = (r.random((h, w, 4)) * 0.8).astype(np.float32)
     yy, xx = np.mgrid[0:h, 0:w]
     for _ in range(8):
         cx, cy, rad = r.integers(0, w), r.integers(0, h), r.integers(2, max(3, w // 8))
         img[((xx - cx) ** 2 + (yy - cy) ** 2) < rad * rad, :3] = r.uniform(1.0, 9.0, 3).astype(np.float32)
+    img[..., :3] *= (0.5 + r.random((h, w, 3))).astype(np.float32)
     img[..., 3] = 0
     return img
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [(160, 80), (200, 120), (96, 54), (333, 77)])
+@pytest.mark.parametrize("size", [(160, 80), (200, 120), (96, 54), (333, 77), (640, 360), (64, 64)])
 def test_gpu_post_matches_oracle(size):
     import raytracing_amd as ra
     w, h = size
     g, po = ra.Renderer(w, h), PostOracle(w, h)
     for f in range(3):
-        a = smooth_hdr(w, h, 100 + f)
+        a = noisy_hdr(w, h, 100 + f)
         g.write_accum(a)
         rgba, rgb8 = g.postprocess(True)
         o_rgba, o_rgb8 = po.run(a)
-        assert np.abs(rgba[..., :3] - o_rgba[..., :3]).max() <= TOL, f
+        assert np.abs(rgba[..., :3] - o_rgba[..., :3]).max() <= TOL_GPU_ORACLE, f
         assert np.abs(rgb8.astype(int) - o_rgb8.astype(int)).max() <= 1
     raw, raw8 = g.postprocess(False)
     assert (raw[..., :3] == a[..., :3]).all()
@@ -67,6 +109,18 @@ def test_gpu_post_matches_reference_fixture():
     for f in range(3):
         g.write_accum(FX["accum%d" % f])
         rgba, rgb8 = g.postprocess(True)
-        assert np.abs(rgba[..., :3] - FX["final%d" % f]).max() <= TOL
+        assert np.abs(rgba[..., :3] - FX["final%d" % f]).max() <= TOL_GPU_REF
         assert np.abs(rgb8.astype(int) - FX["rgb8_%d" % f].astype(int)).max() <= 1
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_frame_loop_matches_reference():
+    """Tracer + bloom chain per frame, as the reference's main loop runs them, against llvmpipe's output."""
+    import raytracing_amd as ra
+    g = ra.Renderer(int(REAL["width"]), int(REAL["height"]))
+    for j, accum, rgba, rgb8 in replay_real(g, lambda _a: g.postprocess(True)):
+        assert (bits(accum[..., :3]) == bits(REAL["accum%d" % j][..., :3])).all()
+        assert np.abs(rgba[..., :3] - REAL["final%d" % j]).max() <= TOL_GPU_REF, j
+        assert np.abs(rgb8.astype(int) - REAL["rgb8_%d" % j].astype(int)).max() <= 1
     g.close()

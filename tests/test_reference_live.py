@@ -48,24 +48,25 @@ from reference_renderer import ReferenceRenderer
 from rt_oracle import PostOracle
 import make_golden as mg
 gl = GLRef()
-for (W, H) in ((320, 160), (200, 120), (250, 130), (123, 77)):
+for (W, H) in ((320, 160), (200, 120), (250, 130), (123, 77), (64, 64), (640, 360)):
     ref, po = ReferenceRenderer(W, H, gl=gl), PostOracle(W, H)
     for frame in range(4):                       # consecutive frames: the tmp texture carries over in both
-        a = mg.boundary_safe_hdr(W, H, 90 + frame)
+        a = mg.noisy_hdr(W, H, 90 + frame)
         ref.write_accum(a)
         rgba, rgb8 = ref.postprocess(True)
         o_rgba, o_rgb8 = po.run(a)
         d = float(np.abs(rgba[..., :3] - o_rgba[..., :3]).max())
         codes = int(np.abs(rgb8.astype(int) - o_rgb8.astype(int)).max())
         print("%dx%d frame %d: max abs diff %.3g, 8-bit codes %d" % (W, H, frame, d, codes))
-        assert d <= 2e-5 and codes <= 1
+        assert d <= 5e-6 and codes <= 1
 print("post chain ok")
 '''
 
 
 def test_bloom_chain_restatement_equals_live_shaders(tmp_path):
     """The bloom chain of the CPU restatement against the reference's own post shaders run on llvmpipe with main.cpp's
-    sequence of passes, at sizes other than the fixture's, four consecutive frames each. Tolerance 2e-5 absolute (llvmpipe
+    sequence of passes, at sizes other than the fixture's (one of them square: pixel centres on the blits' diagonal), four
+    consecutive frames each, on images whose every texel differs from its neighbours. Tolerance 5e-6 absolute (llvmpipe
     approximates pow), 8-bit output within one code."""
     script = tmp_path / "post_live.py"
     script.write_text(POST_LIVE)
