@@ -34,10 +34,12 @@ from raytracing_amd import scenes  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, 8 TB/s
 # Ceilings of the units this kernel actually loads (the scene is cache-resident, so HBM is not one of them):
 SIMDS, CUS = 1024, 256
-ISSUE_CYCLES_PER_INSTRUCTION = 2.2    # one wave64 instruction of any kind per SIMD, measured: tools/microbench/valu_rate.hip
+ISSUE_CYCLES_PER_INSTRUCTION = 2.0    # a SIMD issues a wave64 vector instruction over 2 cycles (32 lanes per cycle): MI355X_MICROARCH.md, hardware model
 L1_ACCESSES_PER_CYCLE_PER_CU = 1.48   # 16-byte lane accesses of a gather the vector L1 serves, measured: tools/microbench/l1_gather.hip
 L2_PEAK_GBS = 34500.0                 # aggregate L2 bandwidth of the 8 XCDs
 L2_BYTES_PER_REQUEST = 128            # a vector-L1 line
+MULTI_SPP_FRAMES, MULTI_SPP_LAUNCHES = 16, 4   # N > 1 only: the extra measurement with several frames per launch
+CARRIED_TIME_TOLERANCE = 0.03         # carried counters describe this run only if its kernel time is within 3 % of the profiled one
 
 WORKLOADS = {
     # name: (scene generator, kwargs, width, height, bounce limit)
@@ -56,40 +58,73 @@ def algorithmic_bytes(c):
             16 * c["sky_fetches"] + 32 * c["paths"])
 
 
-def binding_roofs(workload, avg_ms):
-    """The ceilings that do bound the kernel, each as achieved / peak with the peak's source. The numerators that
-    need hardware counters (instructions, cache accesses per launch) come from the committed rocprofv3 summary of this
-    same command (profiles/counters.json, written by tools/profile_bench.sh + tools/summarize_prof.py); the
-    denominator is this run's own kernel time, and the shader clock is the profile's cycles over the profile's time."""
+def load_carried(workload):
+    """Hardware counters of the dominant kernel, per launch, from the committed rocprofv3 profile of this same command
+    (profiles/counters.json, written by tools/profile_bench.sh + tools/summarize_prof.py). bench.py cannot collect
+    them itself (they need the profiler around the process), so they are carried, and every use is marked as such."""
     cf = os.path.join(ROOT, "profiles", "counters.json")
     if not os.path.exists(cf):
-        return {}
+        return None
     with open(cf) as f:
         c = json.load(f)
     if c.get("workload") != workload or not c.get("kernel_ms_when_profiled"):
-        return {}
+        return None
+    return c
+
+
+def binding_roofs(c, avg_ms):
+    """The ceilings that can bound the kernel, each as achieved / peak with the peak's source; numerators from the
+    carried counters `c`, denominator this run's own kernel time; the shader clock is the profile's cycles over the
+    profile's time. The carried numbers only describe this run if the kernel ran as long as when it was profiled: the
+    check is part of the result, and RT_BENCH_STRICT=1 (set by tools/profile_bench.sh) turns a failed check into an error."""
     clock_hz = c["shader_cycles_per_launch"] / (c["kernel_ms_when_profiled"] * 1e-3)
     sec = avg_ms * 1e-3
+    tag = c.get("profile")
+    drift = avg_ms / c["kernel_ms_when_profiled"] - 1.0
+    ok = abs(drift) <= CARRIED_TIME_TOLERANCE
+    check = "%s: kernel %.4f ms in this run, %.4f ms when profiled (%+.1f %%, tolerance %.0f %%)" % (
+        "ok" if ok else "FAILED", avg_ms, c["kernel_ms_when_profiled"], 100 * drift, 100 * CARRIED_TIME_TOLERANCE)
+    if not ok:
+        print("bench.py: carried counters of profile %s do not describe this run: %s" % (tag, check), file=sys.stderr)
+        if os.environ.get("RT_BENCH_STRICT") == "1":
+            raise SystemExit("carried counters are stale; re-run tools/profile_bench.sh")
     roofs = []
     issue_peak = SIMDS * clock_hz / ISSUE_CYCLES_PER_INSTRUCTION / 1e9
     issue = c["instructions_per_launch"] / sec / 1e9
     roofs.append({"name": "instruction issue", "achieved": round(issue, 1), "peak": round(issue_peak, 1), "unit": "G wave-instructions/s",
-                  "frac": round(issue / issue_peak, 4),
-                  "peak_source": "1024 SIMDs x %.2f GHz / 2.2 cycles per wave64 instruction of any kind (tools/microbench/valu_rate.hip)" % (clock_hz / 1e9)})
+                  "frac": round(issue / issue_peak, 4), "carried_from": tag,
+                  "formula": "instructions_per_launch / kernel time, over 1024 SIMDs x clock / 2 cycles per wave64 instruction",
+                  "peak_source": "1024 SIMDs x %.2f GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: 32 lanes per cycle); "
+                                 "the clock is the profile's shader cycles over its kernel time" % (clock_hz / 1e9)})
+    if c.get("ta_busy_cycles_per_launch"):
+        ta = c["ta_busy_cycles_per_launch"] / sec / 1e9
+        ta_peak = CUS * clock_hz / 1e9
+        roofs.append({"name": "texture-address units busy", "achieved": round(ta, 1), "peak": round(ta_peak, 1), "unit": "G busy cycles/s",
+                      "frac": round(ta / ta_peak, 4), "carried_from": tag,
+                      "formula": "TA_TA_BUSY_sum per launch / kernel time, over 256 units x clock",
+                      "peak_source": "one texture-address unit per CU, busy every cycle"})
     l1_peak = CUS * clock_hz * L1_ACCESSES_PER_CYCLE_PER_CU / 1e9
     l1 = c["vector_l1_accesses_per_launch"] / sec / 1e9
-    roofs.append({"name": "vector L1 / texture-address path", "achieved": round(l1, 1), "peak": round(l1_peak, 1), "unit": "G lane accesses/s",
-                  "frac": round(l1 / l1_peak, 4),
+    roofs.append({"name": "vector L1 gather rate", "achieved": round(l1, 1), "peak": round(l1_peak, 1), "unit": "G lane accesses/s",
+                  "frac": round(l1 / l1_peak, 4), "carried_from": tag,
+                  "formula": "TCP_TOTAL_CACHE_ACCESSES_sum per launch / kernel time, over 256 CUs x clock x 1.48",
                   "peak_source": "256 CUs x %.2f GHz x 1.48 accesses per cycle and CU reached by a 16-byte gather (tools/microbench/l1_gather.hip)" % (clock_hz / 1e9)})
     if c.get("l2_requests_per_launch"):
         l2 = c["l2_requests_per_launch"] * L2_BYTES_PER_REQUEST / sec / 1e9
-        roofs.append({"name": "L2", "achieved": round(l2, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_PEAK_GBS, 4),
+        roofs.append({"name": "L2", "achieved": round(l2, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2 / L2_PEAK_GBS, 4), "carried_from": tag,
+                      "formula": "TCC_REQ_sum x 128 B per launch / kernel time",
                       "peak_source": "aggregate L2 bandwidth, 34.5 TB/s; bytes = TCC_REQ x 128 (a vector-L1 line; uncalibrated, an upper bound)"})
     binding = max(roofs, key=lambda r: r["frac"])
-    return {"roofs": roofs, "binding_roof": {k: binding[k] for k in ("name", "achieved", "peak", "unit", "frac")},
-            "counters": {k: c.get(k) for k in ("profile", "source", "instructions_per_launch", "shader_cycles_per_launch", "vector_l1_accesses_per_launch",
-                                                "l2_hit_rate", "vector_l1_hit_rate", "valu_lane_utilisation", "mean_waves_per_simd",
-                                                "wave_time_waiting", "ta_busy", "kernel_ms_when_profiled")}}
+    valu_share = ISSUE_CYCLES_PER_INSTRUCTION * c["valu_instructions_per_launch"] / (SIMDS * clock_hz * sec) if c.get("valu_instructions_per_launch") else None
+    lane = c.get("valu_lane_utilisation")
+    return {"binding": binding, "roofs": roofs, "carried_ok": ok,
+            "valu_lane_frac": round(valu_share * lane, 4) if valu_share and lane else None,
+            "valu_issue_share": round(valu_share, 4) if valu_share else None,
+            "carried": dict({k: c.get(k) for k in ("instructions_per_launch", "valu_instructions_per_launch", "shader_cycles_per_launch",
+                                                   "vector_l1_accesses_per_launch", "ta_busy_cycles_per_launch", "l2_requests_per_launch",
+                                                   "l2_hit_rate", "vector_l1_hit_rate", "valu_lane_utilisation", "mean_waves_per_simd",
+                                                   "wave_time_waiting", "ta_busy", "kernel_ms_when_profiled")},
+                            carried_from=tag, source=c.get("source"), kernel_ms_this_run=round(avg_ms, 4), check=check)}
 
 
 def llvmpipe_recorded(workload):
@@ -342,6 +377,71 @@ def main():
     else:
         rays, paths, kms_max = float(c["rays"]), float(c["paths"]), kms
 
+    # N > 1: the same exchange with 16 frames per launch and one gather per launch. A launch costs its rays plus an end phase
+    # that depends on the length of single paths, not on their number (about 0.8 ms on this scene), and 1/N shards are small;
+    # several frames per launch amortise that phase, which is how the offline Recorder path renders. Reported beside the
+    # one-frame-per-step headline, never instead of it.
+    multi_spp = None
+    if sharded and MULTI_SPP_FRAMES > 0:
+        spp, launches_m = MULTI_SPP_FRAMES, MULTI_SPP_LAUNCHES
+        seeds_m = scenes.frame_seeds(Wm + K + spp * (launches_m + 1))
+
+        def step_m(j):
+            first = Wm + K + j * spp
+            r.render(first, seeds_m[first:first + spp])
+            if on_device:
+                b = j & 1
+                if gathered_ev[b] is not None:
+                    rs.wait_event(gathered_ev[b])
+                r.export_shard(stage[b].data_ptr())
+                exported = torch.cuda.Event()
+                exported.record(rs)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(exported)
+                if assembled_ev[b] is not None:
+                    cur.wait_event(assembled_ev[b])
+                work = dist.gather(stage[b], gathered[b] if rank == 0 else None, dst=0, async_op=True)
+                work.wait()
+                gathered_ev[b] = torch.cuda.Event()
+                gathered_ev[b].record(cur)
+                if rank == 0:
+                    as_.wait_event(gathered_ev[b])
+                    root.assemble(flats[b].data_ptr(), world)
+                    assembled_ev[b] = torch.cuda.Event()
+                    assembled_ev[b].record(as_)
+            else:
+                b = j & 1
+                r.export_shard(stage[b].data_ptr())
+                finish(j - 1)
+                r.sync()
+                if root is not None:
+                    root.sync()
+                host = stage[b].cpu()
+                parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    flats[b].copy_(torch.cat(parts))
+                pending[b] = True
+
+        step_m(0)                      # warm-up launch
+        fence()
+        r.counters(reset=True)
+        t0m = time.perf_counter()
+        for j in range(1, launches_m + 1):
+            step_m(j)
+        fence()
+        dtm = time.perf_counter() - t0m
+        cm = r.counters(reset=True)
+        sm = torch.tensor([dtm, float(cm["rays"])], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        smax, ssum = sm.clone(), sm.clone()
+        dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+        multi_spp = {"frames_per_launch": spp, "launches": launches_m, "gathers": launches_m,
+                     "value": round(float(ssum[1]) / float(smax[0]) / 1e6, 2), "unit": "Mrays/s",
+                     "ms_per_frame": round(float(smax[0]) / (launches_m * spp) * 1e3, 4),
+                     "note": "same tiles, ranks and gather; %d frames per launch, one gather per launch (the image rank 0 holds is %d frames behind "
+                             "at most); frames of a pixel stay in one lane, results are bit-identical to one frame per launch" % (spp, spp)}
+
     roofline = None
     if sharded and saved_shard is not None:
         # Counting replay of exactly the timed frames, every rank on its own tiles from the state saved above; the
@@ -366,14 +466,33 @@ def main():
         per_step = float(nb[0]) / K
         step_ms = kms_max / K
         achieved = per_step / (step_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                    "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": None,
-                    "note": "whole node: algorithmic bytes of all ranks per step over the slowest rank's kernel time per step, against %d x the HBM "
-                            "peak; as on one GPU the bytes are re-reads served by the caches (frac > 1 on one GPU), so the fraction shows how much of "
-                            "the one-GPU rate survives the sharding, not a distance from an HBM limit" % world,
-                    "kernel": "trace_kernel", "kernel_ms_per_step_slowest_rank": round(step_ms, 4),
-                    "algorithmic_bytes_per_step": int(per_step),
-                    "bytes_per_ray": round(float(nb[0]) / rays, 1), "boxes_per_ray": round(float(nb[1]) / rays, 2), "tris_per_ray": round(float(nb[2]) / rays, 2)}
+        hbm_algorithmic = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                           "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "is_a_bound": False,
+                           "note": "NOT A BOUND: algorithmic bytes of all ranks per step over the slowest rank's kernel time per step, against %d x the HBM "
+                                   "peak; the bytes are re-reads served by the caches" % world,
+                           "algorithmic_bytes_per_step": int(per_step),
+                           "bytes_per_ray": round(float(nb[0]) / rays, 1), "boxes_per_ray": round(float(nb[1]) / rays, 2), "tris_per_ray": round(float(nb[2]) / rays, 2)}
+        carried = load_carried(args.workload)
+        if carried and carried.get("rays_per_launch"):
+            # The kernel is the one-GPU kernel on a 1/N share of the tiles, so its instructions per ray carry over from the one-GPU
+            # profile; priced against N GPUs' issue rate over the slowest rank's kernel time per step.
+            clock_hz = carried["shader_cycles_per_launch"] / (carried["kernel_ms_when_profiled"] * 1e-3)
+            per_ray = carried["instructions_per_launch"] / carried["rays_per_launch"]
+            issue = per_ray * (rays / K) / (step_ms * 1e-3) / 1e9
+            peak = world * SIMDS * clock_hz / ISSUE_CYCLES_PER_INSTRUCTION / 1e9
+            roofline = {"bound": "instruction issue", "achieved": round(issue, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                        "frac": round(issue / peak, 4), "traffic": None, "kernel": "trace_kernel", "kernel_ms_per_step_slowest_rank": round(step_ms, 4),
+                        "carried_from": carried.get("profile"),
+                        "formula": "instructions per ray of the one-GPU profile x rays per step of all ranks / slowest rank's kernel time per step, "
+                                   "over N x 1024 SIMDs x clock / 2 cycles",
+                        "note": "estimate: instructions per ray (%.1f) are carried from the one-GPU profile; small shards spend more of a launch "
+                                "draining, which shows as a lower fraction" % per_ray,
+                        "hbm_algorithmic": hbm_algorithmic}
+        else:
+            roofline = {"bound": "hbm", "achieved": hbm_algorithmic["achieved"], "peak": hbm_algorithmic["peak"], "unit": "GB/s", "frac": hbm_algorithmic["frac"],
+                        "traffic": None, "kernel": "trace_kernel", "kernel_ms_per_step_slowest_rank": round(step_ms, 4),
+                        "note": "no committed one-GPU profile with instructions per ray for this workload (profiles/counters.json): only the algorithmic "
+                                "HBM figure, which is not a bound", "hbm_algorithmic": hbm_algorithmic}
     if not sharded and not args.no_roofline_pass:
         # instrumented replay of exactly the timed frames from the same accumulation state
         r.write_accum(saved)
@@ -394,21 +513,36 @@ def main():
                 t = json.load(f)
             if t.get("workload") == args.workload:
                 traffic = t.get("hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "note": "algorithmic bytes (what the reference shader fetches) are re-reads served by L1/L2/Infinity Cache here (the scene is "
-                            "cache-resident): frac > 1 means HBM does not bound this kernel; 'traffic' is the measured memory-side bytes per launch; "
-                            "the roofs that do bind are under 'roofs', the nearest one under 'binding_roof'",
-                    "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 4),
-                    "algorithmic_bytes_per_launch": int(per_launch),
-                    "bytes_per_ray": round(algorithmic_bytes(ci) / ci["rays"], 1),
-                    "boxes_per_ray": round(ci["boxes_tested"] / ci["rays"], 2),
-                    "tris_per_ray": round(ci["tris_tested"] / ci["rays"], 2),
-                    "lane_use_new_interior_leaf_shade": [round(l / (64.0 * max(1, n)), 3) for l, n in zip(ci["sched_lanes"], ci["sched_rounds"])],
-                    "rounds_new_interior_leaf_shade": [n // launches for n in ci["sched_rounds"]],
-                    "wave_cycles_per_round_new_interior_leaf_shade": [round(64.0 * c / max(1, n)) for c, n in zip(ci["sched_cycles"], ci["sched_rounds"])],
-                    "wave_time_share_new_interior_leaf_shade": [round(c / max(1, sum(ci["sched_cycles"])), 3) for c in ci["sched_cycles"]]}
-        roofline.update(binding_roofs(args.workload, avg_ms))
+        hbm_algorithmic = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                           "is_a_bound": False,
+                           "note": "NOT A BOUND: algorithmic bytes (what the reference shader fetches: 32 B per box test, 48 B per triangle test, ...) over "
+                                   "the kernel time. The scene is cache-resident and these bytes are re-reads served by LDS/L1/L2/Infinity Cache, so the "
+                                   "figure exceeds the HBM peak; 'traffic' beside it is what was measured on the memory side of the L2",
+                           "algorithmic_bytes_per_launch": int(per_launch),
+                           "bytes_per_ray": round(algorithmic_bytes(ci) / ci["rays"], 1),
+                           "boxes_per_ray": round(ci["boxes_tested"] / ci["rays"], 2),
+                           "tris_per_ray": round(ci["tris_tested"] / ci["rays"], 2)}
+        scheduler = {"lane_use_new_interior_leaf_shade": [round(l / (64.0 * max(1, n)), 3) for l, n in zip(ci["sched_lanes"], ci["sched_rounds"])],
+                     "rounds_new_interior_leaf_shade": [n // launches for n in ci["sched_rounds"]],
+                     "wave_cycles_per_round_new_interior_leaf_shade": [round(64.0 * c / max(1, n)) for c, n in zip(ci["sched_cycles"], ci["sched_rounds"])],
+                     "wave_time_share_new_interior_leaf_shade": [round(c / max(1, sum(ci["sched_cycles"])), 3) for c in ci["sched_cycles"]],
+                     "source": "counting variant of the same kernel replaying the timed frames from the same accumulation state (measured in this run)"}
+        carried = load_carried(args.workload)
+        if carried:
+            br = binding_roofs(carried, avg_ms)
+            b = br["binding"]
+            roofline = {"bound": b["name"], "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"], "traffic": traffic,
+                        "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 4), "formula": b["formula"], "peak_source": b["peak_source"],
+                        "carried_from": b["carried_from"], "carried_ok": br["carried_ok"],
+                        "note": "the roof with the highest measured load of those under 'roofs' (none of them is HBM: see 'hbm_algorithmic'); "
+                                "numerators are rocprofv3 counters of the committed profile named in 'carried_from', divided by this run's kernel time",
+                        "valu_lane_frac": br["valu_lane_frac"], "valu_issue_share": br["valu_issue_share"],
+                        "roofs": br["roofs"], "hbm_algorithmic": hbm_algorithmic, "scheduler": scheduler, "carried": br["carried"]}
+        else:
+            roofline = {"bound": "hbm", "achieved": hbm_algorithmic["achieved"], "peak": hbm_algorithmic["peak"], "unit": "GB/s", "frac": hbm_algorithmic["frac"],
+                        "traffic": traffic, "kernel": "trace_kernel", "kernel_avg_ms": round(avg_ms, 4),
+                        "note": "no committed profile for this workload (profiles/counters.json): only the algorithmic HBM figure, which is not a bound",
+                        "hbm_algorithmic": hbm_algorithmic, "scheduler": scheduler}
 
     if rank == 0:
         out = {
@@ -424,6 +558,8 @@ def main():
         }
         if roofline:
             out["roofline"] = roofline
+        if multi_spp:
+            out["multi_spp"] = multi_spp
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(sc, noise, sky, bl, W, H)
         rec = llvmpipe_recorded(args.workload)

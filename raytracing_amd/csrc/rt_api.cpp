@@ -75,6 +75,7 @@ struct rt_context {
     bool orderValid = false;
     uint64_t launchesSinceAlloc = 0;
     uint32_t launchesSinceReduce = 0; // the 32-bit per-wave tallies are folded into the 64-bit totals every few launches
+    uint64_t tileFramesSinceReduce = 0; // frames x tiles per wave traced since the last fold
     uint64_t shardPixels = 0;        // pixels of this shard that lie inside the image
     uint32_t maxWaves = 0;           // persistent grid size limit (resident waves of the device)
     unsigned long long* dTotals = nullptr;   // [kCounterSlots]
@@ -365,6 +366,8 @@ int rt_scene_upload(rt_context* c, const float* tri12, const int32_t* matIdx, ui
 }
 
 namespace {
+// Tile-frames (frames x tiles per wave) after which the 32-bit per-wave tally columns are folded into the 64-bit totals.
+constexpr uint64_t kFoldTileFrames = 4096;
 constexpr float kAirIndex = 1.0003f;     // Fragment.glsl:329
 
 // a / b as the kernels compute it: correctly rounded fp32 with denormal operands read as zero and a denormal
@@ -482,6 +485,17 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
     // (the tile queue heads were cleared by prepare_frames_kernel, which UploadFrames queued just before)
     // The order is rebuilt after launches 1, 2, 4, 8 and then after every 8th: the cost of a tile changes slowly from
     // frame to frame. Only those launches tally rays per tile (one atomic per path, about 1.5 % of a launch).
+    // A launch that alone comes near the fold threshold starts from empty columns; with the full counters on, one
+    // that would exceed it eight times over is refused rather than allowed to wrap.
+    const uint64_t launchTileFrames = (uint64_t)nFrames * ((nGroups + nWaves - 1u) / nWaves);
+    if (!ids && count && launchTileFrames > 8u * kFoldTileFrames)
+        return Fail(c, RT_ERR_UNSUPPORTED, "rt_render: %u frames in one launch are too many for the 32-bit per-wave counters of counting mode; split the launch", nFrames);
+    if (!ids && c->tileFramesSinceReduce != 0 && c->tileFramesSinceReduce + launchTileFrames >= kFoldTileFrames) {
+        LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);
+        HIP_TRY(c, hipGetLastError());
+        c->launchesSinceReduce = 0;
+        c->tileFramesSinceReduce = 0;
+    }
     const uint64_t k = ids ? 0 : c->launchesSinceAlloc + 1;
     const bool reorderAfter = !ids && ((k & (k - 1)) == 0 || (k & 7u) == 0);
     const uint32_t* order = (c->orderValid && !ids) ? c->dOrderVals + c->sp.shardTiles : nullptr;
@@ -493,11 +507,17 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
         if (reorderAfter) { int rc = UpdateTileOrder(c); if (rc != RT_OK) return rc; }
         // a wave's tally column is 32 bits wide: fold the columns into the 64-bit totals before they can wrap
         // (stream-ordered, no host wait; rt_get_counters folds what is left)
-        c->launchesSinceReduce += std::max<uint32_t>(1u, nFrames / 64u);
-        if (c->launchesSinceReduce >= 16u) {
+        // What fills a column is paths per wave: frames x tiles per wave x 64, times the events per path (a few rays;
+        // with the full counters on, some hundred box tests). Folding every 16 launches or every kFoldTileFrames
+        // tile-frames per wave, whichever comes first, leaves three orders of magnitude of headroom at 2000 box tests
+        // per path even if one wave takes eight times its share of the tiles.
+        c->launchesSinceReduce += 1u;
+        c->tileFramesSinceReduce += (uint64_t)nFrames * ((nGroups + nWaves - 1u) / nWaves);
+        if (c->launchesSinceReduce >= 16u || c->tileFramesSinceReduce >= kFoldTileFrames) {
             LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);
             HIP_TRY(c, hipGetLastError());
             c->launchesSinceReduce = 0;
+            c->tileFramesSinceReduce = 0;
         }
     }
     return RT_OK;
@@ -607,6 +627,7 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) try {
     LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);
     HIP_TRY(c, hipGetLastError());
     c->launchesSinceReduce = 0;
+    c->tileFramesSinceReduce = 0;
     const size_t n = (size_t)c->sp.shardTiles * 64;
     if (!c->dIds) HIP_TRY(c, hipMalloc((void**)&c->dIds, n * 3 * sizeof(int32_t)));
     HIP_TRY(c, hipMemsetAsync(c->dIds, 0xff, n * 3 * sizeof(int32_t), c->stream));
@@ -830,10 +851,23 @@ struct rt_group {
     std::vector<rt_context*> ranks;      // sharded contexts, rank r on devices[r]
     rt_context* root = nullptr;          // unsharded context on devices[0]: receives the assembled image
     std::vector<ncclComm_t> comms;
-    void* dGathered = nullptr;           // on devices[0]: world shards back to back
-    hipEvent_t gathered = nullptr;       // recorded on rank 0's stream behind the receives
-    hipEvent_t assembled = nullptr;      // recorded on the root's stream behind the assembly (the next receives wait for it)
-    bool haveAssembled = false;
+    // The exchange runs beside the tracing, not behind it. Per rank: two staging buffers and a stream of its own for the
+    // send. A gather copies the rank's shard into a staging buffer on the tracer's stream (a local copy of a few MB;
+    // the frames queued next follow at once) and sends from there on the communication stream. Rank 0 receives on its
+    // communication stream into one of two receive buffers, and the root context assembles on the root's stream.
+    struct PerRank {
+        hipStream_t comm = nullptr;
+        void* stage[2] = {nullptr, nullptr};
+        hipEvent_t exported[2] = {nullptr, nullptr};   // on the tracer's stream: the shard is in stage[b]
+        hipEvent_t sent[2] = {nullptr, nullptr};       // on the communication stream: stage[b] may be overwritten
+        bool haveSent[2] = {false, false};
+    };
+    std::vector<PerRank> per;
+    void* dGathered[2] = {nullptr, nullptr};           // on devices[0]: world shards back to back
+    hipEvent_t gathered[2] = {nullptr, nullptr};       // on rank 0's communication stream behind the receives
+    hipEvent_t assembled[2] = {nullptr, nullptr};      // on the root's stream behind the assembly (receives into that buffer wait for it)
+    bool haveAssembled[2] = {false, false};
+    uint64_t gathers = 0;
     size_t shardFloats = 0;
     std::string error;
 };
@@ -856,13 +890,27 @@ void rt_group_destroy(rt_group* g) {
     if (!g) return;
     Rccl& nc = LoadRccl();
     for (size_t r = 0; r < g->ranks.size(); ++r) if (g->ranks[r]) (void)rt_sync(g->ranks[r]);
+    for (size_t r = 0; r < g->per.size(); ++r)
+        if (g->per[r].comm) { (void)hipSetDevice(g->devices[r]); (void)hipStreamSynchronize(g->per[r].comm); }
     if (g->root) (void)rt_sync(g->root);
     for (size_t r = 0; r < g->comms.size(); ++r)
         if (g->comms[r] && nc.ok) { (void)hipSetDevice(g->devices[r]); (void)nc.CommDestroy(g->comms[r]); }
+    for (size_t r = 0; r < g->per.size(); ++r) {
+        (void)hipSetDevice(g->devices[r]);
+        rt_group::PerRank& pr = g->per[r];
+        if (pr.comm) { (void)hipStreamSynchronize(pr.comm); (void)hipStreamDestroy(pr.comm); }
+        for (int b = 0; b < 2; ++b) {
+            if (pr.stage[b]) (void)hipFree(pr.stage[b]);
+            if (pr.exported[b]) (void)hipEventDestroy(pr.exported[b]);
+            if (pr.sent[b]) (void)hipEventDestroy(pr.sent[b]);
+        }
+    }
     if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
-    if (g->gathered) (void)hipEventDestroy(g->gathered);
-    if (g->assembled) (void)hipEventDestroy(g->assembled);
-    if (g->dGathered) (void)hipFree(g->dGathered);
+    for (int b = 0; b < 2; ++b) {
+        if (g->gathered[b]) (void)hipEventDestroy(g->gathered[b]);
+        if (g->assembled[b]) (void)hipEventDestroy(g->assembled[b]);
+        if (g->dGathered[b]) (void)hipFree(g->dGathered[b]);
+    }
     for (rt_context* c : g->ranks) rt_destroy(c);
     rt_destroy(g->root);
     delete g;
@@ -891,10 +939,22 @@ int rt_group_create(const int* devices, uint32_t nDevices, uint32_t width, uint3
     int rc = rt_create(devices[0], width, height, &g->root);
     if (rc != RT_OK) return fail(rc, "rt_group_create: root context");
     g->shardFloats = (size_t)g->ranks[0]->sp.shardTiles * 64 * 4;
-    if (hipSetDevice(devices[0]) != hipSuccess || hipMalloc(&g->dGathered, g->shardFloats * sizeof(float) * nDevices) != hipSuccess ||
-        hipEventCreateWithFlags(&g->gathered, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g->assembled, hipEventDisableTiming) != hipSuccess) {
-        g_globalError = "device memory for the gathered shards";
+    const size_t shardBytes = g->shardFloats * sizeof(float);
+    g->per.resize(nDevices);
+    bool ok = true;
+    for (uint32_t r = 0; r < nDevices && ok; ++r) {
+        rt_group::PerRank& pr = g->per[r];
+        ok = hipSetDevice(devices[r]) == hipSuccess && hipStreamCreateWithFlags(&pr.comm, hipStreamNonBlocking) == hipSuccess;
+        for (int b = 0; b < 2 && ok; ++b)
+            ok = hipMalloc(&pr.stage[b], shardBytes) == hipSuccess && hipEventCreateWithFlags(&pr.exported[b], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&pr.sent[b], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipSetDevice(devices[0]) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b)
+        ok = hipMalloc(&g->dGathered[b], shardBytes * nDevices) == hipSuccess && hipEventCreateWithFlags(&g->gathered[b], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&g->assembled[b], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        g_globalError = "device memory, streams or events for the exchange";
         return fail(RT_ERR_DEVICE, "rt_group_create");
     }
     g->comms.assign(nDevices, nullptr);
@@ -923,36 +983,55 @@ int rt_group_gather(rt_group* g) {
     if (!g) return RT_ERR_INVALID;
     Rccl& nc = LoadRccl();
     const uint32_t world = (uint32_t)g->ranks.size();
-    // the previous call's assembly may still be reading the receive buffer on the root's stream
-    if (g->haveAssembled) {
-        HIP_TRY(g->root, hipSetDevice(g->devices[0]));
-        if (hipStreamWaitEvent(g->ranks[0]->stream, g->assembled, 0) != hipSuccess)
-            return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: ordering the receives behind the previous assembly failed");
+    const int b = (int)(g->gathers & 1u);
+    const size_t shardBytes = g->shardFloats * sizeof(float);
+    auto hipFail = [&](const char* what) { return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: %s failed", what); };
+    // 1. every rank copies its shard into stage[b] behind its frames (tracer's stream), once the send of two gathers ago
+    //    has left that buffer; its communication stream waits for the copy
+    for (uint32_t r = 0; r < world; ++r) {
+        rt_group::PerRank& pr = g->per[r];
+        rt_context* c = g->ranks[r];
+        if (hipSetDevice(g->devices[r]) != hipSuccess) return hipFail("hipSetDevice");
+        if (pr.haveSent[b] && hipStreamWaitEvent(c->stream, pr.sent[b], 0) != hipSuccess) return hipFail("ordering the export behind the previous send");
+        if (hipMemcpyAsync(pr.stage[b], c->dAccum, shardBytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return hipFail("exporting the shard");
+        if (hipEventRecord(pr.exported[b], c->stream) != hipSuccess || hipStreamWaitEvent(pr.comm, pr.exported[b], 0) != hipSuccess)
+            return hipFail("ordering the send behind the export");
     }
-    // One group call: every rank sends its shard (behind its frames, on its own stream) to rank 0, which receives them
-    // back to back. Every peer has its own xGMI link to rank 0, so the sends run side by side.
+    // 2. the receives into dGathered[b] wait for the assembly that read it two gathers ago
+    if (hipSetDevice(g->devices[0]) != hipSuccess) return hipFail("hipSetDevice");
+    if (g->haveAssembled[b] && hipStreamWaitEvent(g->per[0].comm, g->assembled[b], 0) != hipSuccess) return hipFail("ordering the receives behind the previous assembly");
+    // 3. one group call: every rank sends from its staging buffer on its communication stream, rank 0 receives the
+    //    shards back to back. Every peer has its own xGMI link to rank 0, so the sends run side by side.
     ncclResult_t nr = nc.GroupStart();
     for (uint32_t r = 0; r < world && nr == ncclSuccess; ++r)
-        nr = nc.Send(g->ranks[r]->dAccum, g->shardFloats, ncclFloat, 0, g->comms[r], g->ranks[r]->stream);
+        nr = nc.Send(g->per[r].stage[b], g->shardFloats, ncclFloat, 0, g->comms[r], g->per[r].comm);
     for (uint32_t r = 0; r < world && nr == ncclSuccess; ++r)
-        nr = nc.Recv(static_cast<float*>(g->dGathered) + (size_t)r * g->shardFloats, g->shardFloats, ncclFloat, (int)r, g->comms[0], g->ranks[0]->stream);
+        nr = nc.Recv(static_cast<float*>(g->dGathered[b]) + (size_t)r * g->shardFloats, g->shardFloats, ncclFloat, (int)r, g->comms[0], g->per[0].comm);
     ncclResult_t ne = nc.GroupEnd();
     if (nr == ncclSuccess) nr = ne;
     if (nr != ncclSuccess) return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: RCCL: %s", nc.GetErrorString(nr));
-    // the root context assembles on its own stream once the receives are done
-    HIP_TRY(g->root, hipSetDevice(g->devices[0]));
-    if (hipEventRecord(g->gathered, g->ranks[0]->stream) != hipSuccess || hipStreamWaitEvent(g->root->stream, g->gathered, 0) != hipSuccess)
-        return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: ordering the assembly behind the receives failed");
-    int rc = rt_accum_assemble(g->root, g->dGathered, world);
+    for (uint32_t r = 0; r < world; ++r) {
+        if (hipSetDevice(g->devices[r]) != hipSuccess || hipEventRecord(g->per[r].sent[b], g->per[r].comm) != hipSuccess) return hipFail("hipEventRecord");
+        g->per[r].haveSent[b] = true;
+    }
+    // 4. the root context assembles on its own stream once the receives are done
+    if (hipSetDevice(g->devices[0]) != hipSuccess) return hipFail("hipSetDevice");
+    if (hipEventRecord(g->gathered[b], g->per[0].comm) != hipSuccess || hipStreamWaitEvent(g->root->stream, g->gathered[b], 0) != hipSuccess)
+        return hipFail("ordering the assembly behind the receives");
+    int rc = rt_accum_assemble(g->root, g->dGathered[b], world);
     if (rc != RT_OK) return GroupFail(g, rc, "rt_group_gather: %s", rt_last_error(g->root));
-    if (hipEventRecord(g->assembled, g->root->stream) != hipSuccess) return GroupFail(g, RT_ERR_DEVICE, "rt_group_gather: hipEventRecord failed");
-    g->haveAssembled = true;
+    if (hipEventRecord(g->assembled[b], g->root->stream) != hipSuccess) return hipFail("hipEventRecord");
+    g->haveAssembled[b] = true;
+    ++g->gathers;
     return RT_OK;
 }
 
 int rt_group_sync(rt_group* g) {
     if (!g) return RT_ERR_INVALID;
     for (rt_context* c : g->ranks) { int rc = rt_sync(c); if (rc != RT_OK) return GroupFail(g, rc, "rt_group_sync: %s", rt_last_error(c)); }
+    for (size_t r = 0; r < g->per.size(); ++r)
+        if (hipSetDevice(g->devices[r]) != hipSuccess || hipStreamSynchronize(g->per[r].comm) != hipSuccess)
+            return GroupFail(g, RT_ERR_DEVICE, "rt_group_sync: communication stream of rank %zu", r);
     int rc = rt_sync(g->root);
     if (rc != RT_OK) return GroupFail(g, rc, "rt_group_sync: %s", rt_last_error(g->root));
     return RT_OK;

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <limits>
 
 namespace rta {
 namespace {
@@ -51,7 +53,15 @@ public:
             v = std::strtof(prefix.c_str(), &end);
             if (end == prefix.c_str()) { failed_ = true; return false; }
         }
-        p_ = q; out = v;
+        p_ = q;
+        if (std::isinf(v)) {
+            // a literal too large for a float: the stream extraction the reference uses stores the largest finite value
+            // and fails, which ends the object (Include/ObjectLoader.h:137-139)
+            out = v > 0 ? std::numeric_limits<float>::max() : -std::numeric_limits<float>::max();
+            failed_ = true;
+            return false;
+        }
+        out = v;
         return true;
     }
     bool Int(int& out) {

@@ -58,3 +58,12 @@ def test_png_with_a_hostile_header_is_refused_without_allocating(tmp_path):
     good = tmp_path / "good.png"
     good.write_bytes(png_with_header(2, 2, zlib.compress((b"\0" + b"\x10\x20\x30" * 2) * 2)))
     assert L.rth_read_png(str(good).encode(), 3, ctypes.byref(w), ctypes.byref(h), None, 0) == 0 and (w.value, h.value) == (2, 2)
+
+
+def test_overflowing_literal_fails_like_stream_extraction(tmp_path):
+    # libstdc++ stores FLT_MAX and sets failbit for a literal beyond the float range; a tiny one just reads as 0 / denormal
+    for bad in ("1e999", "-1e999", "4e38", "1" + "0" * 60):
+        sc = load(tmp_path, HEADER + "2\n" + TRI + "0 0 %s  1 0 0  0 1 0\n" % bad)
+        assert sc.n_triangles == 0 and sc.warnings, bad
+    sc = load(tmp_path, HEADER + "1\n1e-999 3e38 0  1 0 0  0 1 0\n")
+    assert sc.n_triangles == 1 and sc.tri12[0] == 0.0 and sc.tri12[1] > 2.9e38

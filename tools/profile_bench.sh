@@ -7,6 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 # bench.py with its default step counts: the counters then describe the launches the bench line times
+# (the carried-counter check of bench.py is an error here: RT_BENCH_STRICT is set for the final confirming run below)
 ARGS="--no-cpu-baseline --no-roofline-pass $@"
 python3 bench.py $ARGS > $OUT/plain.json 2> $OUT/plain.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/trace.log 2>&1 || exit 1
@@ -21,3 +22,10 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
   timeout -s KILL 240 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc$i -- python3 bench.py $ARGS > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 $OUT/pmc$i.log; exit 1; }
 done
 find $OUT -name "*.csv" | head -50
+# condense, then confirm that a plain run reproduces its roofline from the counters just written
+python3 tools/summarize_prof.py $TAG "$@" > $OUT/summary.log 2>&1 || { tail -5 $OUT/summary.log; exit 1; }
+RT_BENCH_STRICT=1 python3 bench.py "$@" > $OUT/bench_line.json 2> $OUT/bench_line.err || { echo "confirming bench run failed"; tail -5 $OUT/bench_line.err; exit 1; }
+cp $OUT/bench_line.json profiles/bench_$TAG.json
+# gpurun only brings gpurun_out/ back: leave copies of what was written under profiles/ there (copy them to profiles/ at home)
+mkdir -p $OUT/profiles && cp profiles/${TAG}_summary.txt profiles/counters.json profiles/hbm_traffic.json profiles/bench_$TAG.json $OUT/profiles/
+tail -3 $OUT/summary.log; cut -c1-600 $OUT/bench_line.json

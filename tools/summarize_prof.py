@@ -102,10 +102,17 @@ if all(k in v for k in need):
          "mean_waves_per_simd": round(4 * v["SQ_WAVE_CYCLES"] / (cycles * 1024), 3) if "SQ_WAVE_CYCLES" in v else None,
          "wave_time_waiting": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_ANY" in v else None,
          "ta_busy": round(v["TA_TA_BUSY_sum"] / (cycles * 256), 4) if "TA_TA_BUSY_sum" in v else None,
+         "ta_busy_cycles_per_launch": int(v["TA_TA_BUSY_sum"]) if "TA_TA_BUSY_sum" in v else None,
+         "rays_per_launch": bench["config"].get("rays_per_step"),
          "kernel_ms_when_profiled": bench["config"].get("trace_kernel_ms_per_step")}
     json.dump(c, open(os.path.join("profiles", "counters.json"), "w"), indent=1)
-    lines.append("instructions / launch  = %.4g (vector %.4g) in %.4g shader cycles: issue load %.3f of one instruction per 2.2 cycles and SIMD" % (
-        insts, v["SQ_INSTS_VALU"], cycles, insts * 2.2 / (1024 * cycles)))
+    lines.append("instructions / launch  = %.4g (vector %.4g) in %.4g shader cycles: issue load %.3f of one instruction per 2 cycles and SIMD" % (
+        insts, v["SQ_INSTS_VALU"], cycles, insts * 2.0 / (1024 * cycles)))
+    if "TA_TA_BUSY_sum" in v:
+        lines.append("texture-address busy   = TA_TA_BUSY_sum / (cycles * 256 CUs) = %.3f" % (v["TA_TA_BUSY_sum"] / (cycles * 256)))
+    if "SQ_THREAD_CYCLES_VALU" in v:
+        lines.append("VALU lane rate share   = VALU issue share x lane utilisation = %.3f" % (
+            2 * v["SQ_INSTS_VALU"] / (cycles * 1024) * v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64)))
 out = os.path.join("profiles", tag + "_summary.txt")
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[-12:]))
