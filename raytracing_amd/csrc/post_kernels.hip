@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "rt_device.h"
@@ -399,23 +400,23 @@ static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 namespace {
 // The array's address on each device, looked up once per device with that device current. In host code the name
 // `scratch` is only a handle for this lookup; kernels and memsets get the pointer kept here.
-void* g_staticScratch[kMaxStaticDevices];
-bool g_staticScratchKnown[kMaxStaticDevices];
+// (one atomic slot per device, nullptr = not looked up yet: two host threads making their first call on a device at
+// the same time both look the address up and store the same value)
+std::atomic<void*> g_staticScratch[kMaxStaticDevices];
 
 hipError_t StaticScratchOfCurrentDevice(void** out, int* deviceOut) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= kMaxStaticDevices) return hipErrorInvalidDevice;
-    if (!g_staticScratchKnown[dev]) {
-        void* p = nullptr;
+    void* p = g_staticScratch[dev].load(std::memory_order_acquire);
+    if (!p) {
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!p) return hipErrorInvalidSymbol;
-        g_staticScratch[dev] = p;
-        g_staticScratchKnown[dev] = true;
+        g_staticScratch[dev].store(p, std::memory_order_release);
     }
-    *out = g_staticScratch[dev];
+    *out = p;
     if (deviceOut) *deviceOut = dev;
     return hipSuccess;
 }
