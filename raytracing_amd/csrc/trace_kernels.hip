@@ -319,9 +319,6 @@ struct StackRef {
     uint32_t lane;
     const LdsWords4* top;       // the work-group's LDS copy of the first records of `nodes`, in 16-byte units
     uint32_t topBytes;          // how many bytes of `nodes` that copy holds (wave-uniform)
-    uint32_t colAddr;           // LDS byte address of this lane's stack column (entry e at colAddr + e * 512)
-    uint32_t topAddr;           // LDS byte address of the tree-top copy (wave-uniform)
-    uint32_t lane8;             // lane * 8: byte offset of this lane within one spilled stack entry row
 };
 
 // The two halves of the stack (LDS entries as uint2, spilled entries as one 64-bit word) are accessed with
@@ -425,155 +422,6 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     }
 }
 
-#ifndef RT_ASM_STEP
-#define RT_ASM_STEP 1
-#endif
-
-// interior_step + pop_next written out by hand for the builds that keep no counters (the ones that render): the same
-// loads, the same 46 floating-point instructions in the same order and the same stack discipline, without what the
-// compiler adds around divergent source code. What differs from its output:
-//   * the LDS copy and the memory copy of the record are requested together, each under its lane mask, and waited for
-//     once (the compiler waits for the memory loads before it issues the LDS reads, because both write the same
-//     registers);
-//   * one lane mask per decision (left hit, right hit, left first), combined with scalar instructions; the child
-//     taken, the deferred child and the stack height follow from three v_cndmask and one add-with-carry-in;
-//   * the deferred entry is written under one mask, the rare spill to memory is out of line;
-//   * the pop loop is ten instructions per iteration.
-// Registers v64..v86 are temporaries of this block (clobbers); pairs that must be adjacent (the two dwords of a stack
-// entry) are therefore named registers. Every load the block issues is waited for inside it.
-__device__ __forceinline__ void interior_step_asm(const SceneParams& sp, const StackRef& st, Lane& L) {
-    unsigned long long saved, m, a, b;       // lane masks (scalar register pairs)
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        // ---- the record: LDS copy for the top of the tree, memory for the rest ----
-        "v_cmp_gt_u32_e64 %[m], %[topBytes], %[cur]\n\t"
-        "s_mov_b64 exec, %[m]\n\t"
-        "v_add_u32_e32 v82, %[topAddr], %[cur]\n\t"
-        "ds_read_b128 v[64:67], v82\n\t"
-        "ds_read_b128 v[68:71], v82 offset:16\n\t"
-        "ds_read_b128 v[72:75], v82 offset:32\n\t"
-        "ds_read_b64 v[76:77], v82 offset:48\n\t"
-        "s_andn2_b64 exec, %[sv], %[m]\n\t"
-        "global_load_dwordx4 v[64:67], %[cur], %[nodes]\n\t"
-        "global_load_dwordx4 v[68:71], %[cur], %[nodes] offset:16\n\t"
-        "global_load_dwordx4 v[72:75], %[cur], %[nodes] offset:32\n\t"
-        "global_load_dwordx2 v[76:77], %[cur], %[nodes] offset:48\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        // ---- left box: v64..v66 min, v67..v69 max (F:242-263) ----
-        "v_sub_f32_e32 v64, v64, %[ox]\n\t"
-        "v_sub_f32_e32 v65, v65, %[oy]\n\t"
-        "v_sub_f32_e32 v66, v66, %[oz]\n\t"
-        "v_sub_f32_e32 v67, v67, %[ox]\n\t"
-        "v_sub_f32_e32 v68, v68, %[oy]\n\t"
-        "v_sub_f32_e32 v69, v69, %[oz]\n\t"
-        "v_mul_f32_e32 v64, v64, %[ix]\n\t"
-        "v_mul_f32_e32 v65, v65, %[iy]\n\t"
-        "v_mul_f32_e32 v66, v66, %[iz]\n\t"
-        "v_mul_f32_e32 v67, v67, %[ix]\n\t"
-        "v_mul_f32_e32 v68, v68, %[iy]\n\t"
-        "v_mul_f32_e32 v69, v69, %[iz]\n\t"
-        "v_min_f32_e32 v80, v64, v67\n\t"
-        "v_min_f32_e32 v81, v65, v68\n\t"
-        "v_min_f32_e32 v82, v66, v69\n\t"
-        "v_max_f32_e32 v64, v64, v67\n\t"
-        "v_max_f32_e32 v65, v65, v68\n\t"
-        "v_max_f32_e32 v66, v66, v69\n\t"
-        "v_max3_f32 v83, v80, v81, v82\n\t"             // tL
-        "v_min3_f32 v64, v64, v65, v66\n\t"
-        "v_max_f32_e32 v65, 0, v83\n\t"
-        "v_cmp_ge_f32_e64 %[a], v64, v65\n\t"
-        "v_cmp_lt_f32_e64 %[m], v83, %[bestT]\n\t"
-        "s_and_b64 %[a], %[a], %[m]\n\t"               // left child worth visiting
-        // ---- right box: v70..v72 min, v73..v75 max ----
-        "v_sub_f32_e32 v70, v70, %[ox]\n\t"
-        "v_sub_f32_e32 v71, v71, %[oy]\n\t"
-        "v_sub_f32_e32 v72, v72, %[oz]\n\t"
-        "v_sub_f32_e32 v73, v73, %[ox]\n\t"
-        "v_sub_f32_e32 v74, v74, %[oy]\n\t"
-        "v_sub_f32_e32 v75, v75, %[oz]\n\t"
-        "v_mul_f32_e32 v70, v70, %[ix]\n\t"
-        "v_mul_f32_e32 v71, v71, %[iy]\n\t"
-        "v_mul_f32_e32 v72, v72, %[iz]\n\t"
-        "v_mul_f32_e32 v73, v73, %[ix]\n\t"
-        "v_mul_f32_e32 v74, v74, %[iy]\n\t"
-        "v_mul_f32_e32 v75, v75, %[iz]\n\t"
-        "v_min_f32_e32 v80, v70, v73\n\t"
-        "v_min_f32_e32 v81, v71, v74\n\t"
-        "v_min_f32_e32 v82, v72, v75\n\t"
-        "v_max_f32_e32 v70, v70, v73\n\t"
-        "v_max_f32_e32 v71, v71, v74\n\t"
-        "v_max_f32_e32 v72, v72, v75\n\t"
-        "v_max3_f32 v84, v80, v81, v82\n\t"             // tR
-        "v_min3_f32 v70, v70, v71, v72\n\t"
-        "v_max_f32_e32 v71, 0, v84\n\t"
-        "v_cmp_ge_f32_e64 %[b], v70, v71\n\t"
-        "v_cmp_lt_f32_e64 %[m], v84, %[bestT]\n\t"
-        "s_and_b64 %[b], %[b], %[m]\n\t"               // right child worth visiting
-        // ---- which child next, which one deferred (F:296-311) ----
-        "v_cmp_lt_f32_e64 %[m], v83, v84\n\t"           // left first
-        "v_cndmask_b32_e64 v78, v76, v77, %[m]\n\t"     // deferred child: the right one when the left goes first
-        "v_cndmask_b32_e64 v79, v83, v84, %[m]\n\t"     // and its entry distance
-        "s_orn2_b64 %[m], %[m], %[b]\n\t"
-        "s_and_b64 %[m], %[m], %[a]\n\t"               // take the left child: hit, and first or alone
-        "v_cndmask_b32_e64 %[cur], v77, v76, %[m]\n\t"
-        "s_or_b64 %[m], %[a], %[b]\n\t"                // any child
-        "s_and_b64 %[a], %[a], %[b]\n\t"               // both: the deferred entry counts
-        "v_cmp_gt_i32_e32 vcc, %[nLds], %[top]\n\t"
-        "s_and_b64 exec, %[m], vcc\n\t"
-        "v_lshl_add_u32 v82, %[top], 9, %[col]\n\t"
-        "ds_write_b64 v82, v[78:79]\n\t"
-        "s_andn2_b64 %[b], %[a], vcc\n\t"              // both, and the LDS part of the stack is full
-        "s_cbranch_scc1 .Lspill_push%=\n"
-        ".Lpushed%=:\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        "v_addc_co_u32_e64 %[top], vcc, 0, %[top], %[a]\n\t"
-        // ---- lanes without a child to visit take the next deferred node that is still worth it (F:277-283) ----
-        "s_andn2_b64 exec, %[sv], %[m]\n\t"
-        "s_cbranch_execz .Ldone%=\n"
-        ".Lpop%=:\n\t"
-        "v_add_u32_e32 %[top], -1, %[top]\n\t"
-        "v_min_i32_e32 v82, %[nLdsM1], %[top]\n\t"
-        "v_lshl_add_u32 v82, v82, 9, %[col]\n\t"
-        "ds_read_b64 v[80:81], v82\n\t"
-        "v_cmp_lt_i32_e32 vcc, %[nLdsM1], %[top]\n\t"
-        "s_cbranch_vccnz .Lspill_pop%=\n"
-        ".Lpopped%=:\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mov_b32_e32 %[cur], v80\n\t"
-        "v_cmp_nle_f32_e32 vcc, %[bestT], v81\n\t"      // done unless the entry distance is >= the closest hit
-        "s_andn2_b64 exec, exec, vcc\n\t"
-        "s_cbranch_execnz .Lpop%=\n\t"
-        "s_branch .Ldone%=\n"
-        // ---- rare: stack entries beyond the LDS part live in memory ----
-        ".Lspill_push%=:\n\t"
-        "s_mov_b64 exec, %[b]\n\t"
-        "v_add_u32_e32 v82, %[negLds], %[top]\n\t"
-        "v_lshl_add_u32 v82, v82, 9, %[lane8]\n\t"
-        "global_store_dwordx2 v82, v[78:79], %[spill]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_branch .Lpushed%=\n"
-        ".Lspill_pop%=:\n\t"
-        "s_mov_b64 %[b], exec\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
-        "v_add_u32_e32 v82, %[negLds], %[top]\n\t"
-        "v_lshl_add_u32 v82, v82, 9, %[lane8]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "global_load_dwordx2 v[80:81], v82, %[spill]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b64 exec, %[b]\n\t"
-        "s_branch .Lpopped%=\n"
-        ".Ldone%=:\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
-        : [cur] "+v"(L.cur), [top] "+v"(L.top), [sv] "=&s"(saved), [m] "=&s"(m), [a] "=&s"(a), [b] "=&s"(b)
-        : [bestT] "v"(L.bestT), [ox] "v"(L.ray.o.x), [oy] "v"(L.ray.o.y), [oz] "v"(L.ray.o.z),
-          [ix] "v"(L.ray.inv.x), [iy] "v"(L.ray.inv.y), [iz] "v"(L.ray.inv.z),
-          [col] "v"(st.colAddr), [lane8] "v"(st.lane8), [nodes] "s"(sp.nodes), [topBytes] "s"(st.topBytes), [topAddr] "s"(st.topAddr),
-          [spill] "s"(st.spill), [nLds] "n"(kLdsStack), [nLdsM1] "n"(kLdsStack - 1), [negLds] "n"(-kLdsStack)
-        : "memory", "vcc", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
-          "v80", "v81", "v82", "v83", "v84");
-}
-
 // hitTriangle, F:207-234: the distance at which L.ray meets triangle (v0, e1, e2), accepted only if
 // it passes the shader's four early returns (with its comparison operators: NaNs fall through them).
 __device__ __forceinline__ bool hit_triangle(const Ray& r, float4 a, float4 b, float e2z, float& t) {
@@ -642,7 +490,7 @@ __global__ void prepare_frames_kernel(SceneParams sp, FrameParams* __restrict__ 
 // renders one frame, whose parameters then live in scalar registers; ITERS: the shader's iterationsCount is
 // kept (needed by the tallies, the id pass and the heat-map view of bounce limit 0 only).
 template <bool COUNT, bool IDS, bool SINGLE, bool ITERS>
-__global__ __launch_bounds__(64 * RT_WG_WAVES, (4 * RT_MIN_WAVES) / RT_WG_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
+__global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
                                                    float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
                                                    int32_t* __restrict__ ids /* IDS only: [slot][3] */,
                                                    uint2* __restrict__ spillArea /* [gridDim.x][kMaxStack-kLdsStack][64] */,
@@ -660,17 +508,10 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, (4 * RT_MIN_WAVES) / RT_WG_WAVES)
     const uint32_t nTop = min(kTopLds, sp.nInterior);
     StackRef st;
     st.lds = lds_stack + waveInGroup * (uint32_t)(kLdsStack * 64) + lane;
-    {   // this wave's spill area; the wave number is the same in all lanes, and the pointer is moved to scalar registers to say so
-        const unsigned long long p = (unsigned long long)(reinterpret_cast<unsigned long long*>(spillArea) + (size_t)wave * (kMaxStack - kLdsStack) * 64);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p), hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-        st.spill = reinterpret_cast<unsigned long long*>(((unsigned long long)hi << 32) | lo);
-    }
+    st.spill = reinterpret_cast<unsigned long long*>(spillArea) + (size_t)wave * (kMaxStack - kLdsStack) * 64;
     st.lane = lane;
     st.top = (const LdsWords4*)lds_top;
     st.topBytes = nTop * (uint32_t)sizeof(NodeRec);
-    st.colAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)st.lds;
-    st.topAddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) Words4*)lds_top;
-    st.lane8 = lane * 8u;
     st.lds[0] = make_uint2(kNoRef, __float_as_uint(-INFINITY));      // the stopper below every traversal's entries
 
     // the material table is small and read at every hit: keep a copy in LDS
@@ -740,13 +581,13 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, (4 * RT_MIN_WAVES) / RT_WG_WAVES)
             bool descending = at_interior(L.cur);
             do {
                 if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += descending; }
-                if (descending) { if (RT_ASM_STEP && !COUNT && !ITERS) interior_step_asm(sp, st, L); else interior_step<COUNT, ITERS>(sp, st, L, tl); }
+                if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
                 descending = at_interior(L.cur);
                 ++steps;
 #if RT_DOUBLE_STEP
                 // a second node visit before the wave re-counts its lanes: half the loop control per visit
                 if (COUNT) { tl.rounds[1] += (lane == 0); tl.lanes[1] += descending; }
-                if (descending) { if (RT_ASM_STEP && !COUNT && !ITERS) interior_step_asm(sp, st, L); else interior_step<COUNT, ITERS>(sp, st, L, tl); }
+                if (descending) interior_step<COUNT, ITERS>(sp, st, L, tl);
                 descending = at_interior(L.cur);
                 ++steps;
 #endif

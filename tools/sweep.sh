@@ -6,7 +6,7 @@ for v in "$@"; do
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
-        d = json.loads(line); r = d.get('roofline') or {}
+        d = json.loads(line); r = (d.get('roofline') or {}).get('scheduler') or d.get('roofline') or {}
         print('%-12s %8.1f Mrays/s  %7.3f ms/step  use %s  rounds %s  cyc/round %s  share %s' % ('$v', d['value'], d['ms_per_step'], r.get('lane_use_new_interior_leaf_shade'), r.get('rounds_new_interior_leaf_shade'), r.get('wave_cycles_per_round_new_interior_leaf_shade'), r.get('wave_time_share_new_interior_leaf_shade')))
 " || exit 1
 done
