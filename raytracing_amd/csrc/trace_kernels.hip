@@ -376,6 +376,10 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     // (30 % fewer L1 accesses per frame on the benchmark scene).
     float4 n0, n1, n2;
     uint2 refs;                                                       // 56 of the record's 64 bytes are read
+#ifdef RT_PROBE_STEP
+    unsigned long long probeBegin = 0;
+    if (COUNT) probeBegin = __builtin_readcyclecounter();
+#endif
     if (kTopLds > 0 && L.cur < st.topBytes) {
         // (an LDS-qualified pointer: these loads can only become ds_read, and the compiler cannot fold them and the
         // loads of the other branch into FLAT loads from a selected pointer)
@@ -391,6 +395,16 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
         refs = *reinterpret_cast<const uint2*>(N + 3);
     }
     if (COUNT) tl.boxes += 2;
+#ifdef RT_PROBE_STEP
+    // Measurement build only (tools/step_probe.py): where the time of a node visit goes. One lane of a wave adds, in units
+    // of 16 cycles and on top of three of the ordinary tallies, the time from the record request to its data (sky), the
+    // whole visit (noise) and the number of visits (hits).
+    unsigned long long probeData = 0;
+    if (COUNT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        probeData = __builtin_readcyclecounter();
+    }
+#endif
 #ifdef RT_PROBE_TOP
     // Measurement build only (tools/top_probe.py): how many visits go to the first 32 / 64 / 128 / 256 / 1024 / 4096
     // records, added on top of six of the ordinary tallies (subtract the tallies of an ordinary build).
@@ -420,6 +434,15 @@ __device__ __forceinline__ void interior_step(const SceneParams& sp, const Stack
     } else {
         pop_next<COUNT, ITERS>(st, L);
     }
+#ifdef RT_PROBE_STEP
+    if (COUNT) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long probeEnd = __builtin_readcyclecounter();
+        if (st.lane == (uint32_t)__builtin_ctzll(__ballot(true))) {      // one lane of those taking part
+            tl.sky += (uint32_t)((probeData - probeBegin) >> 4); tl.noise += (uint32_t)((probeEnd - probeBegin) >> 4); tl.hits += 1u;
+        }
+    }
+#endif
 }
 
 // hitTriangle, F:207-234: the distance at which L.ray meets triangle (v0, e1, e2), accepted only if
