@@ -141,6 +141,15 @@ int rt_primary_ids(rt_context *ctx, const float *seed3, int32_t *out3);
 int rt_probe_triangles(rt_context *ctx, uint32_t n, const float *tri12, const float *origins3, const float *directions3,
                        uint8_t *hitOut, float *tOut);
 
+/* Parity channel: the plane coefficients with which the bloom chain evaluates a framebuffer blit (glBlitNamedFramebuffer,
+ * src/main.cpp:244-248 and :261-265, as Mesa llvmpipe executes it: two triangles, one plane c0 + cx * x + cy * y per
+ * triangle and texture coordinate, in fp32) from the source rectangle [0,srcW) x [0,srcH) of a texW x texH texture onto
+ * [0,dstW) x [0,dstH) of a surfW x surfH render target. planes12 = {c0, cx, cy} of the horizontal coordinate for the
+ * triangle below and above the rectangle's diagonal, then of the vertical coordinate. Host arithmetic only: needs no
+ * context and no GPU. */
+int rt_probe_blit_planes(uint32_t srcW, uint32_t srcH, uint32_t texW, uint32_t texH, uint32_t dstW, uint32_t dstH,
+                         uint32_t surfW, uint32_t surfH, float *planes12);
+
 /* Bloom chain + final composite of one frame (src/main.cpp:242-275 with
  * extractBrightFragment.glsl, bloomFragment.glsl, finalFragment.glsl); bloom_on == 0 is the
  * raw blit of src/main.cpp:235-240. Either output may be NULL. rgb8_out is what

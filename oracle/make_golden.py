@@ -24,6 +24,7 @@ What is recorded (inputs AND the reference's outputs, as data):
                  what the reference's ObjectLoader/OFFLoader + BvhTree make of them
   ini_reference.npz  ini files written by us (tests/golden/ini/) and what the reference's own ConfigParser (compiled from
                  its sources) returns for them: value lists per key, typed values, exception messages
+  blit_reference.npz  which texels llvmpipe's NEAREST and LINEAR framebuffer blits read (and with which weights), per pixel
   post_*.npz     accumulation images in, the reference's bloom chain (its three post shaders and two blits, run on
                  llvmpipe in main.cpp's order) out; post_real.npz replays the reference's whole frame loop on a scene
 Every file stores a manifest string (Mesa version, flags).
@@ -550,6 +551,68 @@ def ini_fixture():
     print("ini_reference: %d files, %d with a parsing error" % (len(cases), sum(1 for c in cases.values() if c["error"])))
 
 
+def blit_fixture(gl):
+    """Which texels llvmpipe's framebuffer blits read (main.cpp:244-248 NEAREST, :261-265 LINEAR), measured by blitting
+    images that encode their own coordinates: per destination pixel the source texel of a NEAREST down-blit (window
+    sizes up to 3840x2160, all four bloom factors), and the first texel and the weights of a LINEAR up-blit's footprint
+    (small windows: the arrays are window-sized)."""
+    def blit(src_img, W, H, src_rect, dst_rect, linear):
+        src = gl.tex_f32(0, W, H, src_img, linear=True)
+        sfbo = gl.fbo(src)
+        dst = gl.tex_f32(1, W, H, np.full((H, W, 4), -1.0, f32), linear=True)
+        dfbo = gl.fbo(dst)
+        gl.blit(sfbo, dfbo, src_rect, dst_rect, linear=linear)
+        gl.finish()
+        return gl.read_f32(1, dst, W, H)
+
+    def ramp(W, H):
+        img = np.zeros((H, W, 4), f32)
+        img[..., 0] = np.arange(W, dtype=f32)[None, :]
+        img[..., 1] = np.arange(H, dtype=f32)[:, None]
+        return img
+
+    out = {"manifest": manifest(gl)}
+    nearest = []
+    for (W, H), factors in (((1280, 720), (5, 10, 20, 40)), ((1920, 1080), (10, 20, 40)), ((3840, 2160), (10, 20, 40)), ((250, 130), (5, 10)), ((64, 64), (5, 10, 20))):
+        for ds in factors:
+            w, h = W // ds, H // ds
+            got = blit(ramp(W, H), W, H, (0, 0, W, H), (0, 0, w, h), False)[:h, :w]
+            key = "nearest_%dx%d_ds%d" % (W, H, ds)
+            out[key + "_x"] = got[..., 0].astype(np.int16)
+            out[key + "_y"] = got[..., 1].astype(np.int16)
+            nearest.append(key)
+    linear = []
+    for (W, H), ds in (((160, 80), 5), ((160, 80), 20), ((123, 77), 10), ((64, 64), 10)):
+        w, h = W // ds, H // ds
+        xs, ys = np.arange(W), np.arange(H)
+        ca = np.zeros((H, W, 4), f32)
+        ca[..., 0] = (xs % 2)[None, :]
+        ca[..., 1] = (ys % 2)[:, None]
+        r, a, b = (blit(img, W, H, (0, 0, w, h), (0, 0, W, H), True).astype(np.float64) for img in (ramp(W, H), ca, 1 - ca))
+        key = "linear_%dx%d_ds%d" % (W, H, ds)
+        for ch, name in ((0, "x"), (1, "y")):
+            # ramp = first texel + weight (rounded); the weight itself is exact in whichever checkerboard has a 0 at the first texel.
+            # Where the footprint is clamped at the texture's edge both texels coincide; none of these cases reaches it.
+            # A weight next to 1 makes the ramp read as the next integer: of the candidate first texels, the right one is
+            # the one whose weight (read from its checkerboard) reproduces the ramp value, first texel + weight rounded once.
+            base = np.floor(r[..., ch]).astype(np.int64)
+            i0 = np.full(base.shape, -1, np.int64)
+            wgt = np.zeros(base.shape, np.float64)
+            for cand in (base - 1, base, base + 1):
+                wc = np.where(cand % 2 == 0, a[..., ch], b[..., ch])
+                fits = (cand >= 0) & (i0 < 0) & ((cand.astype(np.float64) + wc).astype(f32) == r[..., ch].astype(f32)) & (wc >= 0) & (wc < 1)
+                i0 = np.where(fits, cand, i0)
+                wgt = np.where(fits, wc, wgt)
+            assert (i0 >= 0).all(), "a footprint could not be decoded"
+            out[key + "_i" + name] = i0.astype(np.int16)
+            out[key + "_w" + name] = wgt.astype(f32)
+        linear.append(key)
+    out["nearest_cases"] = np.array(nearest)
+    out["linear_cases"] = np.array(linear)
+    np.savez_compressed(os.path.join(GOLD, "blit_reference.npz"), **out)
+    print("blit_reference: %d NEAREST and %d LINEAR cases" % (len(nearest), len(linear)))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     import tempfile
@@ -560,6 +623,9 @@ def main():
         return
     if "--only-triangle-edges" in sys.argv:
         triangle_edge_fixture(gl)
+        return
+    if "--only-blit" in sys.argv:
+        blit_fixture(gl)
         return
     if "--only-ini" in sys.argv:
         ini_fixture()
@@ -588,6 +654,7 @@ def main():
     triangle_edge_fixture(gl)
     post_fixture(gl)
     post_real_fixture(gl, tmp)
+    blit_fixture(gl)
     ref = RefHost()
     bvh_fixtures(ref)
     loader_fixtures(ref)

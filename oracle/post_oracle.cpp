@@ -258,6 +258,36 @@ void post_run(void* h, const float* accumRGBA, float* rgba_out, uint8_t* rgb8_ou
         }
 }
 
+// The blit arithmetic on its own (for tests): for every pixel of the destination rectangle [0,dw) x [0,dh) of a blit from
+// the source rectangle [0,sw) x [0,sh) of a texW x texH texture, rendered into a surfW x surfH surface, the texel a NEAREST
+// blit reads (ix, iy; wx, wy untouched) or the first texel and the weights of a LINEAR blit's footprint.
+void post_blit_map(int sw, int sh, int texW, int texH, int dw, int dh, int surfW, int surfH, int linear, int32_t* ix, int32_t* iy, float* wx, float* wy) {
+    const BlitPlan b = plan_blit(sw, sh, texW, texH, dw, dh, surfW, surfH);
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            const size_t i = (size_t)y * dw + x;
+            float u, v;
+            blit_coords(b, x, y, u, v);
+            if (!linear) {
+                int sx = (int)u, sy = (int)v;
+                ix[i] = sx < 0 ? 0 : (sx > texW - 1 ? texW - 1 : sx);
+                iy[i] = sy < 0 ? 0 : (sy > texH - 1 ? texH - 1 : sy);
+            } else {
+                u = fmaxf(fminf(u, b.texW) - 0.5f, 0.0f);
+                v = fmaxf(fminf(v, b.texH) - 0.5f, 0.0f);
+                const float fu = floorf(u), fv = floorf(v);
+                ix[i] = (int)fu; iy[i] = (int)fv; wx[i] = u - fu; wy[i] = v - fv;
+            }
+        }
+}
+
+// The fitted planes themselves: c0, cx, cy of the horizontal coordinate for the two triangles, then of the vertical one.
+void post_blit_planes(int sw, int sh, int texW, int texH, int dw, int dh, int surfW, int surfH, float* planes12) {
+    const BlitPlan b = plan_blit(sw, sh, texW, texH, dw, dh, surfW, surfH);
+    const Plane* p[4] = {&b.s[0], &b.s[1], &b.t[0], &b.t[1]};
+    for (int k = 0; k < 4; ++k) { planes12[3 * k] = p[k]->a0; planes12[3 * k + 1] = p[k]->dadx; planes12[3 * k + 2] = p[k]->dady; }
+}
+
 // One bloom level image after the up-blit (for tests).
 void post_level(void* h, int i, float* rgb_out) {
     Post* p = (Post*)h;

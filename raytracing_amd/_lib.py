@@ -64,6 +64,7 @@ SIGNATURES = {
     "rt_sync": (I, [P]),
     "rt_primary_ids": (I, [P, P, P]),
     "rt_probe_triangles": (I, [P, U32, P, P, P, P, P]),
+    "rt_probe_blit_planes": (I, [U32] * 8 + [P]),
     "rt_postprocess": (I, [P, I, P, P]),
     "rt_postprocess_static": (I, [P, U32, U32, P, P, P]),
     "rt_display_read": (I, [P, P, P]),

@@ -432,6 +432,17 @@ int PrepareStaticScratch() {
 }
 }  // namespace rtd
 
+extern "C" int rt_probe_blit_planes(uint32_t srcW, uint32_t srcH, uint32_t texW, uint32_t texH, uint32_t dstW, uint32_t dstH, uint32_t surfW, uint32_t surfH,
+                                    float* planes12) {
+    using namespace rtd;
+    if (!planes12 || !srcW || !srcH || !texW || !texH || !dstW || !dstH || !surfW || !surfH ||
+        (srcW | srcH | texW | texH | dstW | dstH | surfW | surfH) > 32768u) { SetGlobalError("rt_probe_blit_planes: bad argument"); return RT_ERR_INVALID; }
+    const BlitMap m = MakeBlitMap((int)srcW, (int)srcH, (int)texW, (int)texH, (int)dstW, (int)dstH, (int)surfW, (int)surfH);
+    const BlitPlane* p[4] = {&m.u[0], &m.u[1], &m.v[0], &m.v[1]};
+    for (int k = 0; k < 4; ++k) { planes12[3 * k] = p[k]->c0; planes12[3 * k + 1] = p[k]->cx; planes12[3 * k + 2] = p[k]->cy; }
+    return RT_OK;
+}
+
 extern "C" int rt_postprocess_static(const float* accumDevice, uint32_t width, uint32_t height, float* rgbaOutDevice, uint8_t* rgb8OutDevice,
                                      void* hipStream) {
     using namespace rtd;

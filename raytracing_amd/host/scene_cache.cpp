@@ -243,6 +243,8 @@ bool WriteSceneBlob(const std::string& path, const uint8_t key[32], const SceneD
     return ok;
 }
 
+uint64_t SceneBlobChecksum(const uint8_t* bytes, size_t n) { return Checksum(bytes, n); }
+
 bool ReadSceneBlob(const std::string& path, const uint8_t key[32], SceneData& s) {
     MappedFile file(path);
     if (!file.ok() || file.size() < sizeof(BlobHeader) + 8) return false;

@@ -36,5 +36,7 @@ SceneData LoadSceneCached(const std::vector<std::string>& objectPaths, int build
 bool SceneCacheKey(const std::vector<std::string>& objectPaths, uint8_t key[32]);
 bool WriteSceneBlob(const std::string& path, const uint8_t key[32], const SceneData& scene);
 bool ReadSceneBlob(const std::string& path, const uint8_t key[32], SceneData& scene);
+// The checksum a blob ends in (over everything before it), so that a test can build blobs with a forged header.
+uint64_t SceneBlobChecksum(const uint8_t* bytes, size_t n);
 
 }  // namespace rta

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <dirent.h>
 #include <fstream>
 #include <random>
@@ -108,6 +109,36 @@ int main(int argc, char** argv) {
             return 1;
         }
         ++calls;
+    }
+
+    // 2b. forged headers with a valid checksum: counts chosen so that the size the header implies wraps around to the file's
+    // real size (offsets: nTri 40, nNode 44, nMaterials 48, nWarnings 52, warningBytes 96 in the 104-byte header)
+    {
+        auto forged = [&](size_t offset, uint64_t value, size_t width) {
+            std::string v = blob;
+            std::memcpy(&v[offset], &value, width);
+            const uint64_t sum = SceneBlobChecksum(reinterpret_cast<const uint8_t*>(v.data()), v.size() - 8);
+            std::memcpy(&v[v.size() - 8], &sum, 8);
+            return v;
+        };
+        uint32_t nTri = 0, nNode = 0, nMat = 0;
+        uint64_t warnBytes = 0;
+        std::memcpy(&nTri, &blob[40], 4); std::memcpy(&nNode, &blob[44], 4); std::memcpy(&nMat, &blob[48], 4); std::memcpy(&warnBytes, &blob[96], 8);
+        std::vector<std::string> cases;
+        // one more material, paid for by "negative" warning bytes: the sum is the file size again
+        cases.push_back(forged(96, warnBytes - 44, 8));
+        { std::string v = cases.back(); const uint32_t m = nMat + 1; std::memcpy(&v[48], &m, 4); const uint64_t sum = SceneBlobChecksum(reinterpret_cast<const uint8_t*>(v.data()), v.size() - 8); std::memcpy(&v[v.size() - 8], &sum, 8); cases.back() = v; }
+        cases.push_back(forged(96, ~0ull - 1000, 8));                   // warning bytes far beyond the file
+        cases.push_back(forged(48, 0xffffffffu, 4));                     // four billion materials
+        cases.push_back(forged(40, 0x01000000u, 4));                     // more triangles than indices can address
+        cases.push_back(forged(44, 0xfffffff0u, 4));                     // nodes far beyond the file
+        cases.push_back(forged(52, 0xffffffffu, 4));                     // more warnings than warning bytes
+        for (const std::string& v : cases) {
+            WriteAll(scratch + "/forged.rtscene", v);
+            SceneData s;
+            if (ReadSceneBlob(scratch + "/forged.rtscene", key, s)) { fprintf(stderr, "scene cache: a blob with a forged header was accepted\n"); return 1; }
+            ++calls;
+        }
     }
 
     // 3. PNG reader
