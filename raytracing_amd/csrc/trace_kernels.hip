@@ -210,6 +210,17 @@ __device__ __forceinline__ Texels fetch_sky(const SceneParams& sp, V3 dir) {
     return q;
 }
 
+// Whether `p` holds in any of the lanes that execute the call; used only to skip memory requests no lane needs, so an
+// answer of "yes" is safe whenever some lane hit something. (The tests' host build of this file runs lanes one by one and
+// cannot tell which lanes share a divergent branch: there every lane answers for itself.)
+__device__ __forceinline__ bool any_lane(bool p) {
+#ifdef RT_HOST_EMULATION
+    return p;
+#else
+    return __ballot(p) != 0ull;
+#endif
+}
+
 // Moves a value that is equal in all lanes into a scalar register.
 __device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 __device__ __forceinline__ V3 uni3(V3 v) { return mk(uni(v.x), uni(v.y), uni(v.z)); }
@@ -229,7 +240,11 @@ __device__ __forceinline__ bool hit_box(const Ray& r, float mnx, float mny, floa
     // max(lo, 0) as the one v_max_f32 it is: written as fmaxf the compiler first re-quiets `lo` with a second
     // v_max_f32, which the three-operand maximum that produced it has already done.
     float lo0;
+#ifdef RT_HOST_EMULATION      // (the tests' host build of this file: same value, lo being a maximum of minima, NaN only if all are)
+    lo0 = fmaxf(lo, 0.0f);
+#else
     asm("v_max_f32_e32 %0, 0, %1" : "=v"(lo0) : "v"(lo));
+#endif
     return hi >= lo0;
 }
 
@@ -679,13 +694,13 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                     float ta_w = 0.0f, tc_x = 0.0f, tc_y = 0.0f;      // (initialised so that nothing is carried between rounds)
                     float4 tb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     Texels nA = {0u, 0u, 0u, 0u, 0, 0}, sk = {0u, 0u, 0u, 0u, 0, 0};
-                    if (__ballot(hitAnything) != 0ull) {
+                    if (any_lane(hitAnything)) {
                         const TriRec* T = reinterpret_cast<const TriRec*>(reinterpret_cast<const char*>(sp.tris) +
                                                                           mul24(hitAnything ? (uint32_t)L.bestIdx : 0u, (uint32_t)sizeof(TriRec)));
                         ta_w = T->e1x; tb = *reinterpret_cast<const float4*>(&T->e1y); tc_x = T->e2z; tc_y = __int_as_float(T->material);
                         nA = fetch_noise(sp, seedx + 0.01534f, seedy + 0.183f);      // F:420
                     }
-                    if (__ballot(!hitAnything) != 0ull) sk = fetch_sky(sp, L.ray.d);  // F:410-411
+                    if (any_lane(!hitAnything)) sk = fetch_sky(sp, L.ray.d);  // F:410-411
                     if (!hitAnything) {
                         if (COUNT) tl.sky += (i == 0) ? 2u : 1u;
                         result = L.throughput * resolve3(sk);                        // F:410-413

@@ -1,0 +1,257 @@
+"""The product's own kernels and host code on the CPU: the HIP sources compiled as host C++ against stand-in headers
+(tests/emu), lanes run as fibers that meet at every wave-wide operation, checked against the same oracle and to the same
+bar (bit for bit) as the GPU tests. What this covers that the oracle-only CPU tests cannot: the scheduler, the on-chip and
+spilled stack, the tile queues, record building, sharding and the exchange between devices (with an in-process imitation
+of RCCL). What it cannot cover: the compiler's device code, the hardware's division and square-root sequences
+(exact_div.h; the host build divides), timing. Sizes are small: a lane here costs about a microsecond per step."""
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from emulation import Emulated
+from raytracing_amd import scenes, sharding
+from rt_oracle import Oracle, PostOracle
+from test_gpu_parity import _chain_scene
+from test_post import TOL_GPU_ORACLE, noisy_hdr
+from util import DEFAULT_CAMERA, bits, differing_pixels, make_scene, setup
+
+NOISE = scenes.noise_texture(64, 48)
+SKY = scenes.sky_cubemap(32)
+SEEDS = scenes.frame_seeds(12)
+
+CASES = [
+    ("lightbox", {}, 40, 24),
+    ("sponza_like", {"target_tris": 6000}, 45, 27),      # neither side a multiple of 8
+]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emulated_module():
+    with Emulated(devices=3):
+        yield
+
+
+@pytest.fixture(scope="module", params=CASES, ids=[c[0] for c in CASES])
+def pair(request):
+    name, kw, W, H = request.param
+    sc = make_scene(name, **kw)
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    setup(g, sc, NOISE, SKY)
+    setup(o, sc, NOISE, SKY)
+    yield g, o, sc
+    g.close()
+
+
+def test_it_is_the_emulated_library_that_runs():
+    from raytracing_amd import _lib
+    assert _lib.lib()._name.endswith("librt_emulated.so")
+
+
+def test_primary_ids_bit_exact(pair):
+    g, o, _ = pair
+    a, b = g.primary_ids(SEEDS[0]), o.primary_ids(SEEDS[0])
+    assert (a == b).all()
+    assert (a[..., 0] >= 0).any()
+
+
+@pytest.mark.parametrize("bounce_limit,frames", [(0, 1), (1, 1), (2, 3), (8, 2), (16, 1)])
+def test_radiance_bit_exact(pair, bounce_limit, frames):
+    g, o, _ = pair
+    for r in (g, o):
+        r.set_bounce_limit(bounce_limit)
+        r.clear()
+        r.render(0, SEEDS[:frames])
+    a, b = g.read_accum(), o.read_accum()
+    assert np.isfinite(b[..., :3]).all()
+    assert differing_pixels(a, b) == 0
+    assert (a[..., 3] == 0).all()
+
+
+def test_progressive_split_equals_batch_and_counters_match(pair):
+    g, o, _ = pair
+    for r in (g, o):
+        r.set_bounce_limit(4)
+        r.clear()
+    g.set_counting(True)
+    g.counters(reset=True); o.counters(reset=True)
+    g.render(0, SEEDS[:4]); o.render(0, SEEDS[:4])
+    whole = g.read_accum()
+    cg, co = g.counters(reset=True), o.counters(reset=True)
+    g.set_counting(False)
+    for k in ("rays", "node_pops", "boxes_tested", "tris_tested", "noise_fetches", "sky_fetches", "hits"):
+        assert cg[k] == co[k], k
+    assert cg["paths"] == g.W * g.H * 4
+    assert sum(cg["sched_lanes"]) > 0 and cg["sched_rounds"][1] > 0
+    g.clear()
+    for k in range(4):
+        g.render(k, SEEDS[k:k + 1])
+    assert differing_pixels(whole, g.read_accum()) == 0
+    assert differing_pixels(whole, o.read_accum()) == 0
+    assert g.counters(reset=True)["rays"] == co["rays"]
+
+
+def test_empty_and_single_leaf_scenes():
+    W, H = 24, 16
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    one = np.array([[4, -1, -1, 0, 4, 1, -1, 0, 4, 0, 1, 0]], dtype=np.float32)
+    node = np.array([[4, 1, 1, 4, -1, -1, 1, 0]], dtype=np.float32)
+    mats = np.array([[0.8, 0.3, 0.2, 1, 1, 1, 1, 0, 0, 0, 0]], dtype=np.float32)
+    for tri12, matidx, node8 in ((np.zeros((0, 12), np.float32), np.zeros(0, np.int32), np.zeros((0, 8), np.float32)),
+                                 (one, np.zeros(1, np.int32), node)):
+        for r in (g, o):
+            r.set_scene(tri12, matidx, node8)
+            r.set_materials(mats)
+            r.set_camera(**DEFAULT_CAMERA)
+            r.set_noise(NOISE)
+            r.set_skybox(SKY)
+        for bl in (0, 1, 4):
+            for r in (g, o):
+                r.set_bounce_limit(bl)
+                r.clear()
+                r.render(0, SEEDS[:2])
+            assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+        assert (g.primary_ids(SEEDS[0]) == o.primary_ids(SEEDS[0])).all()
+    g.close()
+
+
+def test_deepest_tree_spills_the_stack_bit_exact():
+    """Interior nodes 63 levels deep, both children entered at every level: 51 of a lane's deferred nodes live in the
+    spill area (Fragment.glsl:9,270); one level more is refused at upload."""
+    tri12, matidx, node8 = _chain_scene(63)
+    mats = np.array([[0.8, 0.6, 0.3, 1, 1, 1, 1, 0, 0, 0, 0]], dtype=np.float32)
+    W, H = 24, 16
+    camera = dict(DEFAULT_CAMERA, viewport_width=0.5)
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    for r in (g, o):
+        r.set_scene(tri12, matidx, node8)
+        r.set_materials(mats)
+        r.set_camera(**camera)
+        r.set_noise(NOISE)
+        r.set_skybox(SKY)
+        r.set_bounce_limit(4)
+    a, b = g.primary_ids(SEEDS[0]), o.primary_ids(SEEDS[0])
+    assert (a == b).all()
+    assert (a[..., 0] == 63).all() and (a[..., 2] >= 2 * 63).all()
+    for r in (g, o):
+        r.render(0, SEEDS[:2])
+    assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+    with pytest.raises(ra.RtError, match="63"):
+        g.set_scene(*_chain_scene(64))
+    g.close()
+
+
+def test_glass_deck_bit_exact():
+    """A deck of parallel quads, some of glass: long paths through many overlapping boxes, deferred nodes beyond the
+    on-chip entries on the way."""
+    n = 6000
+    x = (1.0 + 0.003 * np.arange(n, dtype=np.float64)).astype(np.float32)
+    lo, hi = np.float32(-6.0), np.float32(6.0)
+    tri9 = np.zeros((2 * n, 9), dtype=np.float32)
+    tri9[0::2] = np.stack([x, np.full(n, lo), np.full(n, lo), x, np.full(n, hi), np.full(n, lo), x, np.full(n, hi), np.full(n, hi)], 1)
+    tri9[1::2] = np.stack([x, np.full(n, lo), np.full(n, lo), x, np.full(n, hi), np.full(n, hi), x, np.full(n, lo), np.full(n, hi)], 1)
+    mats = np.zeros((2, 11), dtype=np.float32)
+    mats[0] = [0.8, 0.7, 0.6, 1, 1, 1, 1.0, 0.0, 0.0, 0.0, 0]
+    mats[1] = [0.9, 0.9, 1.0, 1, 1, 1, 0.0, 0.5, 0.9, 1.5, 0]
+    slots = (np.arange(2 * n) // 2 % 7 != 0).astype(np.int32)
+    sc = ra.build_scene(tri9, slots, mats, build_threads=2)
+    assert sc.stats["max_depth"] >= 13
+    W, H = 32, 16
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    for r in (g, o):
+        setup(r, sc, NOISE, SKY, bounce_limit=3)
+        r.render(0, SEEDS[:2])
+    assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+    assert (g.primary_ids(SEEDS[0]) == o.primary_ids(SEEDS[0])).all()
+    g.close()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (8, 70), (5, 33), (150, 9), (1, 65)], ids=lambda s: "%dx%d" % s)
+def test_extreme_image_shapes_alone_and_in_three_shards(size):
+    W, H = size
+    sc = make_scene("sponza_like", target_tris=6000)
+    o = Oracle(W, H)
+    setup(o, sc, NOISE, SKY, bounce_limit=3)
+    o.render(0, SEEDS[:2])
+    want = o.read_accum()
+    g = ra.Renderer(W, H)
+    setup(g, sc, NOISE, SKY, bounce_limit=3)
+    g.render(0, SEEDS[:2])
+    assert differing_pixels(g.read_accum(), want) == 0
+    g.close()
+    world = 3
+    per = sharding.shard_floats(W, H, world)
+    flat = np.zeros(world * per, dtype=np.float32)
+    for rank in range(world):
+        r = ra.Renderer(W, H)
+        setup(r, sc, NOISE, SKY, bounce_limit=3)
+        r.set_shard(rank, world)
+        r.render(0, SEEDS[:2])
+        part = np.empty(per, dtype=np.float32)
+        r.export_shard(part.ctypes.data); r.sync()          # "device" memory is host memory here
+        flat[rank * per:(rank + 1) * per] = part
+        r.close()
+    assert differing_pixels(sharding.assemble_numpy(flat, W, H, world), want) == 0
+
+
+def test_tile_order_feedback_changes_nothing(pair):
+    """After the first launches the tiles are handed out most expensive first (costs from earlier launches, sorted on
+    the device): the image must not depend on it."""
+    g, o, _ = pair
+    for r in (g, o):
+        r.set_bounce_limit(4)
+        r.clear()
+    for k in range(10):
+        g.render(k, SEEDS[k:k + 1])
+    o.render(0, SEEDS[:10])
+    assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+
+
+def test_group_of_three_devices_equals_unsharded():
+    """rt_group with three ranks: sharded contexts, staging buffers, sends and receives (imitated RCCL: a send without its
+    receive, or sizes that differ, is an error), double-buffered receive, assembly on the root."""
+    W, H = 52, 36
+    sc = make_scene("sponza_like", target_tris=6000)
+    g = ra.Group([0, 1, 2], W, H)
+    assert len(g.ranks) == 3
+    for r in g.ranks:
+        setup(r, sc, NOISE, SKY, bounce_limit=4)
+    o = Oracle(W, H)
+    setup(o, sc, NOISE, SKY, bounce_limit=4)
+    g.render(0, SEEDS[:2]); g.gather(); g.sync()
+    o.render(0, SEEDS[:2])
+    assert differing_pixels(g.root.read_accum(), o.read_accum()) == 0
+    for k in range(2, 7):                       # render + gather pairs queued back to back: both halves of every double buffer
+        g.render(k, SEEDS[k:k + 1])
+        g.gather()
+    g.sync()
+    o.render(2, SEEDS[2:7])
+    assert differing_pixels(g.root.read_accum(), o.read_accum()) == 0
+    g.render(7, SEEDS[7:12]); g.gather(); g.sync()      # a multi-frame launch between gathers
+    o.render(7, SEEDS[7:12])
+    assert differing_pixels(g.root.read_accum(), o.read_accum()) == 0
+    assert sum(r.counters()["rays"] for r in g.ranks) == o.counters()["rays"]
+    rgba, _ = g.root.postprocess(True)
+    assert np.isfinite(rgba).all()
+    with pytest.raises(ra.RtError):
+        ra.Group([0, 0], W, H)
+    with pytest.raises(ra.RtError):
+        ra.Group([0, 3], W, H)                  # the imitated runtime has three devices
+    g.close()
+
+
+@pytest.mark.parametrize("size", [(96, 54), (33, 17)])
+def test_bloom_chain_matches_oracle(size):
+    """The post kernels (threshold, blits, blur, composite) on the host: same tolerance as on the GPU; pow() is libm's
+    here, the hardware's exp2/log2 there."""
+    w, h = size
+    g, po = ra.Renderer(w, h), PostOracle(w, h)
+    for f in range(3):
+        a = noisy_hdr(w, h, 100 + f)
+        g.write_accum(a)
+        rgba, rgb8 = g.postprocess(True)
+        o_rgba, o_rgb8 = po.run(a)
+        assert np.abs(rgba[..., :3] - o_rgba[..., :3]).max() <= TOL_GPU_ORACLE, f
+        assert np.abs(rgb8.astype(int) - o_rgb8.astype(int)).max() <= 1
+    raw, raw8 = g.postprocess(False)
+    assert (bits(raw[..., :3]) == bits(a[..., :3])).all()
+    g.close()
