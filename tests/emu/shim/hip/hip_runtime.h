@@ -67,6 +67,11 @@ static inline uint32_t emu_mbcnt(uint32_t mask, uint32_t add, unsigned shift) {
 #define __builtin_amdgcn_mbcnt_hi(mask, add) emu_mbcnt((mask), (add), 32u)
 
 static inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline uint32_t atomicMax(uint32_t* p, uint32_t v) {
+    uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
 
 // ---- wave- and block-wide operations: every lane that is still running must arrive at the same one ----
