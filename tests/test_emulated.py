@@ -255,3 +255,53 @@ def test_bloom_chain_matches_oracle(size):
     raw, raw8 = g.postprocess(False)
     assert (bits(raw[..., :3]) == bits(a[..., :3])).all()
     g.close()
+
+
+def test_entry_point_that_allocates_nothing_equals_the_ordinary_one():
+    """rt_postprocess_static on two images in a row, the second smaller (both share the library's fixed array), against
+    rt_postprocess: the same kernels on the same values, so bit for bit."""
+    import ctypes
+    from raytracing_amd import _lib
+    from test_zz_no_alloc import hdr_image, reference_chain
+    L = _lib.lib()
+    for img in (hdr_image(160, 90, 1), hdr_image(51, 29, 2), hdr_image(3, 2, 4)):
+        h, w = img.shape[:2]
+        rgba = np.full((h, w, 4), -1.0, dtype=np.float32)
+        rgb8 = np.full((h, w, 3), 7, dtype=np.uint8)
+        rc = L.rt_postprocess_static(img.ctypes.data, w, h, rgba.ctypes.data, rgb8.ctypes.data, None)
+        assert rc == 0, L.rt_last_global_error().decode()
+        want_rgba, want_rgb8 = reference_chain(img)
+        assert (bits(rgba) == bits(want_rgba)).all()
+        assert (rgb8 == want_rgb8).all()
+    assert L.rt_postprocess_static(img.ctypes.data, 8000, 4500, None, rgb8.ctypes.data, None) == -4
+    assert L.rt_postprocess_static(None, 3, 2, None, rgb8.ctypes.data, None) == -1
+
+
+def test_tallies_are_folded_before_they_can_wrap():
+    """The per-wave tally columns are 32 bits wide and folded into 64-bit totals every 4096 tile-frames per wave: a fold
+    before a launch that would cross the line, one after a launch that crossed it, and a counting launch far beyond it
+    refused. One tile, an empty scene: every path is one ray into the sky."""
+    W = H = 8
+    g = ra.Renderer(W, H)
+    g.set_scene(np.zeros((0, 12), np.float32), np.zeros(0, np.int32), np.zeros((0, 8), np.float32))
+    g.set_materials(np.array([[0.8, 0.3, 0.2, 1, 1, 1, 1, 0, 0, 0, 0]], dtype=np.float32))
+    g.set_camera(**DEFAULT_CAMERA)
+    g.set_noise(NOISE)
+    g.set_skybox(SKY)
+    g.set_bounce_limit(4)
+    seeds = scenes.frame_seeds(9000)
+    g.counters(reset=True)
+    first = 0
+    for n in (1500, 1500, 1500, 4200, 3):
+        g.render(first, seeds[first:first + n])
+        first += n
+    c = g.counters(reset=True)
+    assert c["rays"] == first * W * H and c["paths"] == first * W * H
+    g.set_counting(True)
+    g.render(first, seeds[first:first + 200])
+    c = g.counters(reset=True)
+    assert c["rays"] == c["paths"] == c["sky_fetches"] // 2 == 200 * W * H      # primary rays that miss look the sky up twice
+    with pytest.raises(ra.RtError, match="split the launch"):
+        g.render(0, np.zeros((8 * 4096 + 1, 3), np.float32))
+    g.set_counting(False)
+    g.close()
