@@ -3,7 +3,7 @@
 // operation (ballot, shuffle, readfirstlane, barrier), "device" memory is host memory, streams run synchronously.
 // What it is for: running the product's own kernel and host code under a debugger, a sanitizer and the CPU test
 // suite, against the same oracle the GPU tests use. What it is not: a way to ship or time anything. The library
-// built from it carries another name and is loaded by tests/test_emulated_*.py alone.
+// built from it carries another name and is loaded by the tests alone (tests/emulation.py).
 #pragma once
 
 #include <math.h>

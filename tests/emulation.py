@@ -10,7 +10,8 @@ import subprocess
 from raytracing_amd import _lib
 
 EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
-EMU_LIB = os.path.join(EMU_DIR, "_build", "librt_emulated.so")
+EMU_BUILD = os.environ.get("RT_EMU_BUILD", "_build")           # "_build_asan": the AddressSanitizer build (tests/emu/Makefile)
+EMU_LIB = os.path.join(EMU_DIR, EMU_BUILD, "librt_emulated.so")
 _loaded = None
 
 
@@ -18,7 +19,7 @@ def library():
     """Builds (if stale) and loads the emulated library, with the package's signature table applied."""
     global _loaded
     if _loaded is None:
-        r = subprocess.run(["make", "-C", EMU_DIR, "-j4"], capture_output=True, text=True)
+        r = subprocess.run(["make", "-C", EMU_DIR, "-j4"] + (["asan"] if EMU_BUILD == "_build_asan" else ["B=" + EMU_BUILD]), capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("building the emulated library failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
         L = ctypes.CDLL(EMU_LIB)

@@ -48,3 +48,24 @@ def test_host_readers_survive_damaged_files_under_sanitizers(tmp_path):
     run = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "objects"), str(scratch), png, ini], capture_output=True, text=True, timeout=900, env=env)
     assert run.returncode == 0, (run.stdout[-2000:] + run.stderr[-6000:])
     assert "host_sanitize:" in run.stdout
+
+
+def test_kernels_on_the_host_emulation_under_address_sanitizer():
+    """The library's kernels and C ABI compiled as host C++ (tests/emu) with AddressSanitizer, on a selection of the
+    emulated parity cases: device buffers are heap blocks there, so a kernel or host index past the end of one (tally
+    columns, spill rows, tile order, staging and receive buffers of a device group, the fixed post-processing array) is
+    reported instead of passing by luck. Skipped where clang's sanitizer runtime is missing."""
+    import glob
+    import sys
+    runtimes = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not runtimes:
+        pytest.skip("no AddressSanitizer runtime for clang here")
+    env = dict(os.environ, RT_EMU_BUILD="_build_asan", LD_PRELOAD=runtimes[-1],
+               ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0")
+    cases = "(radiance and lightbox) or deepest or glass or three_devices or folded or allocates or (shapes and 5x33)"
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_emulated.py"), "-q", "-x", "-p", "no:cacheprovider", "-k", cases],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    out = run.stdout[-3000:] + run.stderr[-6000:]
+    assert "ERROR: AddressSanitizer" not in run.stdout + run.stderr, out
+    assert run.returncode == 0, out
+    assert " passed" in run.stdout and "failed" not in run.stdout, out
