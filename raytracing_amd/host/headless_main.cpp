@@ -7,7 +7,9 @@
 //                      [--keys "K4 W+ 10 W- 50"] [--poses file --spp 256] [--out shots] [--no-bloom] [--flip]
 //                      [--offline [--rank r --world n]] [--cache dir]
 // --gpus N: one image on GPUs 0..N-1 of this process (tile sharding, shards gathered over RCCL: rt_group_*); renders
-// --frames frames from the default camera (no key replay, no poses) and writes <out>.png.
+// --frames frames from the default camera (no key replay, no poses) and writes <out>.png. The bloom chain runs once, on the
+// gathered image; the plain loop runs it for every displayed frame and carries its tmp texture over as the reference does,
+// so with bloom on the two write the same image for --frames 1 only (without bloom: for any number of frames).
 // --cache: keep the parsed objects and the built tree in that directory, keyed by the object files' bytes.
 // --poses alone replays the Recorder's playback frame by frame (one launch and one bloom pass per displayed frame, as
 // the reference does). --poses with --offline is the batch form: all samples of a pose in one launch, images written by

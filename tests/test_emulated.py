@@ -305,3 +305,39 @@ def test_tallies_are_folded_before_they_can_wrap():
         g.render(0, np.zeros((8 * 4096 + 1, 3), np.float32))
     g.set_counting(False)
     g.close()
+
+
+def test_headless_executable_on_three_imitated_devices_writes_the_same_image(tmp_path):
+    """The C++ host program (ini -> PNG textures -> objects -> frames -> bloom -> PNG) linked against the emulated library:
+    a plain context against --gpus 3 (rt_group: three sharded ranks, gather to the root context, bloom chain there), with
+    the scene cache on."""
+    import os
+    import subprocess
+    from PIL import Image
+    from emulation import EMU_DIR, EMU_BUILD
+    W, H = 48, 32
+    objects = scenes.write_objects(scenes.lightbox(), str(tmp_path / "objs"))
+    root = tmp_path / "install"
+    (root / "Sky").mkdir(parents=True)
+    for f, name in enumerate(("right", "left", "top", "bottom", "front", "back")):
+        Image.fromarray(SKY[f], "RGBA").save(str(root / "Sky" / (name + ".png")))
+    Image.fromarray(NOISE, "RGB").save(str(root / "noise.png"))
+    scenes.write_ini(str(root / "RayTracer.ini"), os.path.dirname(objects[0]), [os.path.basename(p) for p in objects], skybox_path=str(root / "Sky"))
+    exe = os.path.join(EMU_DIR, EMU_BUILD, "raytracer_headless_emulated")
+    common = [exe, "--ini", str(root / "RayTracer.ini"), "--noise", str(root / "noise.png"), "--width", str(W), "--height", str(H),
+              "--cache", str(tmp_path / "cache")]
+    env = dict(os.environ, RT_EMU_DEVICES="3")
+    # (with bloom the plain loop runs the chain per displayed frame and carries its tmp texture over, the group once on the
+    # gathered image: same image for one frame only; without bloom for any number of frames)
+    for tag, extra in (("bloom1", ["--frames", "1"]), ("plain5", ["--frames", "5", "--no-bloom"])):
+        one = subprocess.run(common + extra + ["--out", str(tmp_path / ("one" + tag))], capture_output=True, text=True, timeout=300, env=env)
+        assert one.returncode == 0, one.stdout + one.stderr
+        grp = subprocess.run(common + extra + ["--gpus", "3", "--out", str(tmp_path / ("grp" + tag))], capture_output=True, text=True, timeout=300, env=env)
+        assert grp.returncode == 0, grp.stdout + grp.stderr
+        assert "on 3 GPUs" in grp.stdout and len(os.listdir(str(tmp_path / "cache"))) == 1
+        a, b = np.asarray(Image.open(str(tmp_path / ("one" + tag + ".png")))), np.asarray(Image.open(str(tmp_path / ("grp" + tag + ".png"))))
+        assert a.shape == (H, W, 3) and a.max() > 40
+        assert (a == b).all(), tag
+    extra = ["--frames", "1"]
+    four = subprocess.run(common + extra + ["--gpus", "4", "--out", str(tmp_path / "four")], capture_output=True, text=True, timeout=300, env=env)
+    assert four.returncode != 0 and "device" in (four.stdout + four.stderr).lower()      # more ranks than devices: refused, not crashed
