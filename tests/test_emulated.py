@@ -341,3 +341,34 @@ def test_headless_executable_on_three_imitated_devices_writes_the_same_image(tmp
     extra = ["--frames", "1"]
     four = subprocess.run(common + extra + ["--gpus", "4", "--out", str(tmp_path / "four")], capture_output=True, text=True, timeout=300, env=env)
     assert four.returncode != 0 and "device" in (four.stdout + four.stderr).lower()      # more ranks than devices: refused, not crashed
+
+
+# ---- the bodies of GPU tests that need no torch device, run here against the emulated library ----
+import test_app_gpu
+import test_gpu_golden
+import test_post
+import test_video_gpu
+
+
+@pytest.mark.parametrize("path", test_gpu_golden.FIXTURES, ids=[p.split("tracer_")[-1][:-4] for p in test_gpu_golden.FIXTURES])
+def test_kernels_reproduce_the_llvmpipe_fixtures(path):
+    """Ids, hit distances, heat map, normals and multi-frame radiance as the reference's shader rendered them on llvmpipe:
+    the product's kernel source, on the host, bit for bit."""
+    test_gpu_golden.test_gpu_reproduces_reference_fixture(path)
+
+
+def test_reference_frame_loop_tracer_and_bloom_chain():
+    """The reference's main loop on the light box (tracer draw + bloom chain per frame, 16 frames): tracer bit-exact, chain
+    within the GPU test's tolerance of llvmpipe's output."""
+    test_post.test_gpu_frame_loop_matches_reference()
+    test_post.test_gpu_post_matches_reference_fixture()
+
+
+def test_headless_app_ticks_keys_and_recorder(tmp_path):
+    objects = scenes.write_objects(scenes.lightbox(), str(tmp_path / "objs"))
+    test_app_gpu.test_ticks_equal_direct_rendering(objects)
+    test_app_gpu.test_keys_restart_accumulation(objects)
+
+
+def test_offline_video_path_matches_tracer_and_post_oracle(tmp_path):
+    test_video_gpu.test_every_pose_matches_tracer_and_post_oracle(tmp_path)
