@@ -42,6 +42,22 @@ def pair(request):
     g.close()
 
 
+def test_the_emulation_itself():
+    """Wave- and block-wide operations return what the hardware returns (ballot over running lanes only, shuffle, first
+    lane, mbcnt, a barrier that orders two waves); lanes that reach different wave-wide operations, and waves that can never
+    complete one, end the process with a message instead of a wrong answer."""
+    import os
+    import subprocess
+    from emulation import EMU_BUILD, EMU_DIR, library
+    library()
+    exe = os.path.join(EMU_DIR, EMU_BUILD, "selftest")
+    ok = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and "0 wrong values" in ok.stdout, ok.stdout + ok.stderr
+    for mode, message in (("divergent", "different wave-wide operations"), ("deadlock", "deadlock")):
+        r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=120)
+        assert r.returncode == -6 and message in r.stderr, (mode, r.returncode, r.stderr)
+
+
 def test_it_is_the_emulated_library_that_runs():
     from raytracing_amd import _lib
     assert _lib.lib()._name.endswith("librt_emulated.so")
