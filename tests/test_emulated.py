@@ -388,3 +388,22 @@ def test_headless_app_ticks_keys_and_recorder(tmp_path):
 
 def test_offline_video_path_matches_tracer_and_post_oracle(tmp_path):
     test_video_gpu.test_every_pose_matches_tracer_and_post_oracle(tmp_path)
+
+
+@pytest.mark.parametrize("cus,threads", [(1, 1), (3, 2), (40, 4)])
+def test_any_grid_size_gives_the_same_image(cus, threads):
+    """The persistent grid is sized to the machine: one work-group that takes every tile, a few, and far more waves than
+    tiles (most find their queue empty at once). Frames 0..5 in launches of 1, 2 and 3, so that the tile order is rebuilt
+    in between."""
+    W, H = 56, 24          # 21 tiles
+    sc = make_scene("sponza_like", target_tris=6000)
+    o = Oracle(W, H)
+    setup(o, sc, NOISE, SKY, bounce_limit=8)
+    o.render(0, SEEDS[:6])
+    with Emulated(devices=1, cus=cus, threads=threads):
+        g = ra.Renderer(W, H)
+        setup(g, sc, NOISE, SKY, bounce_limit=8)
+        g.render(0, SEEDS[:1]); g.render(1, SEEDS[1:3]); g.render(3, SEEDS[3:6])
+        assert differing_pixels(g.read_accum(), o.read_accum()) == 0
+        assert g.counters()["rays"] == o.counters()["rays"]
+        g.close()
