@@ -20,8 +20,10 @@ GENS = [("lightbox", {}), ("sponza_like", {"target_tris": 6000}), ("sponza_like"
         ("dragon_like", {"target_tris": 8000}), ("teapot_like", {"target_tris": 9000})]
 
 
-def run(cases, seed, large=False, log=print):
-    """Runs `cases` random configurations; returns how many of them differ from the oracle."""
+def run(cases, seed, large=False, log=print, host_buffers=False):
+    """Runs `cases` random configurations; returns how many of them differ from the oracle. host_buffers: shards are
+    exported into host arrays instead of torch device tensors (for the host emulation of the library, whose device memory
+    is host memory)."""
     rng = np.random.default_rng(seed)
     noises = [scenes.noise_texture(64, 48), scenes.noise_texture(37, 23, seed=5), scenes.noise_texture()]
     skies = [scenes.sky_cubemap(32), scenes.sky_cubemap(17, seed=9)]
@@ -61,14 +63,19 @@ def run(cases, seed, large=False, log=print):
             got = g.read_accum()
             g.close()
         else:
-            import torch
             per = sharding.shard_floats(W, H, world)
             flat = np.zeros(world * per, dtype=np.float32)
             for rank in range(world):
                 g = traced(rank)
-                t = torch.empty(per, dtype=torch.float32, device="cuda")
-                g.export_shard(t.data_ptr()); g.sync()
-                flat[rank * per:(rank + 1) * per] = t.cpu().numpy()
+                if host_buffers:
+                    part = np.empty(per, dtype=np.float32)
+                    g.export_shard(part.ctypes.data); g.sync()
+                    flat[rank * per:(rank + 1) * per] = part
+                else:
+                    import torch
+                    t = torch.empty(per, dtype=torch.float32, device="cuda")
+                    g.export_shard(t.data_ptr()); g.sync()
+                    flat[rank * per:(rank + 1) * per] = t.cpu().numpy()
                 g.close()
             got = sharding.assemble_numpy(flat, W, H, world)
         n = differing_pixels(got, want)

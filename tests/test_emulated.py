@@ -407,3 +407,13 @@ def test_any_grid_size_gives_the_same_image(cus, threads):
         assert differing_pixels(g.read_accum(), o.read_accum()) == 0
         assert g.counters()["rays"] == o.counters()["rays"]
         g.close()
+
+
+def test_random_configurations_bit_exact():
+    """The randomised parity check of the GPU tests (random scene, image size, camera, bounce limit 0-32, launch split,
+    1-5 shards) on the emulated library, with seeds of its own."""
+    import fuzz_parity
+    lines = []
+    bad = fuzz_parity.run(24, 31, log=lines.append, host_buffers=True)
+    assert bad == 0, "\\n".join(l for l in lines if "DIFFERS" in l)
+    assert sum("shards 1" not in l for l in lines[:-1]) >= 4      # sharded cases were among them
