@@ -138,6 +138,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        if "emulated" in os.path.basename(LIB_PATH):
+            raise RuntimeError("RT_LIB_PATH names the tests' host emulation of the library: the package only loads builds of the HIP library")
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "librt_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

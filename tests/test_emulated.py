@@ -417,3 +417,15 @@ def test_random_configurations_bit_exact():
     bad = fuzz_parity.run(24, 31, log=lines.append, host_buffers=True)
     assert bad == 0, "\\n".join(l for l in lines if "DIFFERS" in l)
     assert sum("shards 1" not in l for l in lines[:-1]) >= 4      # sharded cases were among them
+
+
+def test_the_package_itself_never_loads_the_emulated_library():
+    """RT_LIB_PATH (kernel-tuning builds of the HIP library) cannot be pointed at the emulation: only the tests put it under
+    the Python layer, by hand."""
+    import os
+    import subprocess
+    import sys
+    from emulation import EMU_LIB
+    r = subprocess.run([sys.executable, "-c", "import raytracing_amd._lib as l; l.lib()"], env=dict(os.environ, RT_LIB_PATH=EMU_LIB),
+                       capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode != 0 and "host emulation" in r.stderr

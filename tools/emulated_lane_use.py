@@ -3,13 +3,18 @@ a Sponza-like scene, with about eight tiles per wave as in the 4K benchmark. Cou
 which round is decided by ballots, which the emulation reproduces; only the assignment of tiles to waves differs from a
 GPU run. Usage: EMU_SO=<path to a librt_emulated.so> python tools/emulated_lane_use.py"""
 import os, sys, time
-os.environ["RT_LIB_PATH"] = os.environ["EMU_SO"]
+import ctypes
 os.environ["RT_EMU_CUS"] = os.environ.get("RT_EMU_CUS", "8"); os.environ["RT_EMU_THREADS"] = "3"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, ROOT + "/tests", ROOT + "/oracle"):
     sys.path.insert(0, p)
 import numpy as np
 import raytracing_amd as ra
+from raytracing_amd import _lib
+_emulated = ctypes.CDLL(os.environ["EMU_SO"])            # put under the Python layer by hand, as the tests do: the package itself refuses it
+for _name, (_res, _args) in _lib.SIGNATURES.items():
+    getattr(_emulated, _name).restype, getattr(_emulated, _name).argtypes = _res, _args
+_lib._lib = _emulated
 from raytracing_amd import scenes
 from util import make_scene, setup
 NOISE = scenes.noise_texture(64, 48); SKY = scenes.sky_cubemap(32); SEEDS = scenes.frame_seeds(8)
