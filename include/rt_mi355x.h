@@ -110,6 +110,16 @@ int rt_set_camera(rt_context *ctx, const rt_camera *camera);
  * 0 = BVH heat map, 1 = |normal| of the primary hit, n >= 2 = path tracing. */
 int rt_set_bounce_limit(rt_context *ctx, uint32_t bounceLimit);
 
+/* Replaces the shader's compile-time constant RAY_COUNT (src/shaders/Fragment.glsl:5, used by the loop of
+ * Fragment.glsl:459-483): rays traced per pixel and frame. Ray i takes its pixel jitter at u_RandSeed.yz + 0.007 i and
+ * adds Hash(i) to both per-bounce seeds; from the second ray on the loop skips up to three rays when a ray's colour is
+ * close to the sum of those before it, and the frame's colour is the mean of the rays traced. The reference is checked
+ * in with 1, which is also the default here; values above 1 reproduce the shader recompiled with that constant.
+ * 1 <= rays <= RT_MAX_RAY_COUNT. Takes effect with the next rt_render; the caller restarts its accumulation
+ * (frame index 0) as it would after any change of the shader. rt_primary_ids always describes ray 0. */
+#define RT_MAX_RAY_COUNT 64u
+int rt_set_ray_count(rt_context *ctx, uint32_t rays);
+
 /* Replaces LoadNoiseTexture (src/main.cpp:89-114): RGB8, rows bottom-up as uploaded to GL
  * (i.e. in file order, the reference does not flip), LINEAR filter, REPEAT wrap. */
 int rt_set_noise(rt_context *ctx, const uint8_t *rgb, uint32_t width, uint32_t height);

@@ -31,6 +31,7 @@ ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--camera", default="", help="px,py,pz,fx,fy,fz: position and facing (normalised here); default = the reference's start pose")
 ap.add_argument("--fov", type=float, default=120.0, help="field of view in degrees (the reference uses 120, and 90 with the C key)")
+ap.add_argument("--ray-count", type=int, default=1, help="the shader's compile-time RAY_COUNT (Fragment.glsl:5): rays per pixel and frame")
 ap.add_argument("--skip-seeds", type=int, default=0, help="start this many draws into the seed stream")
 args = ap.parse_args()
 W, H = args.width, args.height
@@ -67,8 +68,9 @@ ib = o.primary_ids(seeds[0])
 hit = ia[..., 2] > 0
 print("primary hits: %d pixels; triangle ids differing: %d; hit distances differing: %d" % (
     int(hit.sum()), int((ia[..., 0].astype(np.int32)[hit] != ib[..., 0][hit]).sum()), int((bits(ia[..., 1])[hit] != ib[..., 1].view(np.uint32)[hit]).sum())))
-ref = ReferenceRenderer(W, H, gl=gl)
+ref = ReferenceRenderer(W, H, gl=gl, ray_count=args.ray_count)
 setup(ref)
+o.set_ray_count(args.ray_count)
 ref.clear()
 o.clear()
 worst = 0

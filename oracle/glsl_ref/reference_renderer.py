@@ -5,10 +5,11 @@ TEST INFRASTRUCTURE ONLY (fixture generation in the build container; needs /root
 This module replaces the reference's src/main.cpp for that purpose: it issues the same GL calls
 in the same order — accumulation FBO, scene buffers, material/camera/bounce uniforms, one
 full-screen draw per frame with u_FrameIndex / u_RandSeed, and the bloom chain — against the
-UNMODIFIED shader files under <reference>/src/shaders. The only optional change is one textual
-substitution (`ids=True`) that makes the tracer's normal-view return
+UNMODIFIED shader files under <reference>/src/shaders. The only optional changes are one of two textual
+substitutions made in memory while the file is loaded: `ids=True` makes the tracer's normal-view return
 (Fragment.glsl:389) emit (triangle index, t, hitAnything) instead of |normal|, because the
-reference has no output that carries triangle ids.
+reference has no output that carries triangle ids; `ray_count=n` sets the shader's own compile-time
+constant RAY_COUNT (Fragment.glsl:5, checked in as 1) to n.
 """
 import os
 
@@ -21,6 +22,7 @@ SHADERS = os.path.join(REFERENCE, "src", "shaders")
 
 _IDS_FIND = "return vec3(abs(hitRecord.normal));"
 _IDS_REPL = "return vec3(float(hitRecord.index), hitRecord.t, hitAnything ? 1.0 : 0.0);"
+_RAYS_FIND = "#define RAY_COUNT 1\n"
 
 # texture units (any distinct values work; the reference hands them out with a counter)
 U_ACCUM, U_SKY, U_NOISE, U_MATIDX, U_BOXES, U_TMP, U_BLOOM0 = 0, 1, 2, 3, 4, 5, 6
@@ -29,13 +31,17 @@ DOWNSAMPLE = (5, 10, 20, 40, 80, 160)   # src/main.cpp:183
 
 
 class ReferenceRenderer:
-    def __init__(self, width, height, ids=False, gl=None):
+    def __init__(self, width, height, ids=False, gl=None, ray_count=1):
         self.gl = gl or GLRef()
         self.W, self.H = width, height
         g = self.gl
         vs = os.path.join(SHADERS, "Vertex.glsl")
         fs = os.path.join(SHADERS, "Fragment.glsl")
-        self.prog = g.program(vs, fs, _IDS_FIND if ids else None, _IDS_REPL if ids else None)
+        assert not (ids and ray_count != 1), "the loader makes one substitution"
+        if ray_count != 1:
+            self.prog = g.program(vs, fs, _RAYS_FIND, "#define RAY_COUNT %d\n" % int(ray_count))
+        else:
+            self.prog = g.program(vs, fs, _IDS_FIND if ids else None, _IDS_REPL if ids else None)
         g.u2f(self.prog, "screenResolution", float(width), float(height))          # main.cpp:38-39
         self.accum = g.tex_f32(U_ACCUM, width, height, None, linear=False)            # main.cpp:148-158
         self.fbo = g.fbo(self.accum)

@@ -9,6 +9,9 @@ What is recorded (inputs AND the reference's outputs, as data):
                  output under llvmpipe: BVH heat map (bounce limit 0), |normal| view (1), progressive
                  radiance for several bounce limits, plus primary-hit (index, t) from the one-line
                  id patch described in oracle/glsl_ref/reference_renderer.py
+  raycount_*.npz the same inputs, and the tracer shader's output when its own compile-time constant RAY_COUNT
+                 (Fragment.glsl:5, checked in as 1) is set to 2..6 while the file is loaded: the loop over a pixel's rays with
+                 its per-ray jitter, per-ray seed term and early-out (Fragment.glsl:459-485)
   texture_*.npz  texture() results of llvmpipe for the noise-texture and cube-map samplers
   sky_rotation.npz  the tracer's whole sky lookup, texture(u_Skybox, RotateAroundAxis(dir, (1,0,0), -3.1415/2)), run on
                  llvmpipe with the reference's own RotateAroundAxis (its text is read from the reference's shader at
@@ -99,6 +102,40 @@ def tracer_fixture(gl, name, sc, W, H, camera, noise, sky, radiance_cases, n_see
     out["manifest"] = manifest(gl)
     np.savez_compressed(os.path.join(GOLD, "tracer_%s.npz" % name), **out)
     print("tracer_%s: %d tris, %dx%d, hit pixels %d" % (name, sc.n_triangles, W, H, int((out["ids_index"] >= 0).sum())))
+
+
+def ray_count_fixture(gl, name, sc, W, H, camera, noise, sky, cases, n_seeds=8):
+    """cases: (ray count, bounce limit, frames). One program per ray count: the constant is part of the shader text."""
+    seeds = scenes.frame_seeds(n_seeds)
+    out = dict(tri12=sc.tri12, matidx=sc.matidx, node8=sc.node8, materials=sc.materials, noise=noise, sky=sky,
+               cam_position=np.asarray(camera["position"], f32), cam_facing=np.asarray(camera["facing"], f32),
+               cam_fov=f32(camera["fov"]), cam_vpw=f32(camera["viewport_width"]), width=W, height=H, seeds=seeds)
+    for rays in sorted({c[0] for c in cases}):
+        ref = ReferenceRenderer(W, H, gl=gl, ray_count=rays)
+        ref.set_scene(sc.tri12, sc.matidx, sc.node8)
+        ref.set_materials(sc.materials)
+        ref.set_camera(**camera)
+        ref.set_noise(noise)
+        ref.set_skybox(sky)
+        for r, bl, frames in cases:
+            if r != rays:
+                continue
+            ref.clear()
+            ref.set_bounce_limit(bl)
+            ref.render(0, seeds[:frames])
+            out["radiance_r%d_b%d_f%d" % (rays, bl, frames)] = ref.read_accum()[..., :3].copy()
+    out["manifest"] = manifest(gl) + "; RAY_COUNT set in memory at load time"
+    np.savez_compressed(os.path.join(GOLD, "raycount_%s.npz" % name), **out)
+    print("raycount_%s: %d tris, %dx%d, %d cases" % (name, sc.n_triangles, W, H, len(cases)))
+
+
+def ray_count_fixtures(gl, tmp, noise, sky, zoom):
+    ray_count_fixture(gl, "lightbox", scene_from(scenes.lightbox(), tmp + "/ra"), 64, 36, DEFAULT_CAMERA, noise, sky,
+                      [(2, 4, 3), (5, 8, 2), (3, 1, 1), (3, 0, 1)])
+    ray_count_fixture(gl, "sponza_small", scene_from(scenes.sponza_like(target_tris=6000), tmp + "/rb"), 72, 40, DEFAULT_CAMERA, noise, sky,
+                      [(4, 8, 3)])
+    ray_count_fixture(gl, "dragon_small", scene_from(scenes.dragon_like(target_tris=4000), tmp + "/rc"), 48, 32, zoom, noise, sky,
+                      [(3, 16, 2), (6, 4, 1)])
 
 
 def texture_fixture(gl):
@@ -636,10 +673,13 @@ def main():
         return
     noise = scenes.noise_texture(64, 48, seed=7)
     sky = scenes.sky_cubemap(32, seed=3)
-    cam2 = dict(position=(1.5, -2.0, 0.7), facing=tuple(float(x) for x in (np.array([0.8, 0.55, -0.2], f32) / np.linalg.norm(np.array([0.8, 0.55, -0.2], f32)))),
-                fov=float(FOV), viewport_width=VPW)
     zoom = dict(DEFAULT_CAMERA)
     zoom["viewport_width"] = float(f32(2.0 * np.tan(float(f32(90 * 0.01745329251994329576923690768489)) / 2.0)))   # the C key: 90 degrees
+    if "--only-ray-count" in sys.argv:
+        ray_count_fixtures(gl, tmp, noise, sky, zoom)
+        return
+    cam2 = dict(position=(1.5, -2.0, 0.7), facing=tuple(float(x) for x in (np.array([0.8, 0.55, -0.2], f32) / np.linalg.norm(np.array([0.8, 0.55, -0.2], f32)))),
+                fov=float(FOV), viewport_width=VPW)
     tracer_fixture(gl, "lightbox", scene_from(scenes.lightbox(), tmp + "/a"), 96, 54, DEFAULT_CAMERA, noise, sky,
                    [(2, 4), (4, 16), (8, 4), (32, 2)])
     tracer_fixture(gl, "lightbox_cam2", scene_from(scenes.lightbox(), tmp + "/a2"), 72, 40, cam2, noise, sky, [(4, 6)])
@@ -649,6 +689,7 @@ def main():
                    [(16, 8)])
     tracer_fixture(gl, "teapot_small", scene_from(scenes.teapot_like(target_tris=4000), tmp + "/d"), 70, 38, DEFAULT_CAMERA, noise, sky,
                    [(8, 8)])
+    ray_count_fixtures(gl, tmp, noise, sky, zoom)
     texture_fixture(gl)
     sky_rotation_fixture(gl)
     triangle_edge_fixture(gl)

@@ -29,6 +29,7 @@ def _load():
     L.orc_set_materials.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     L.orc_set_camera.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float]
     L.orc_set_bounce_limit.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    L.orc_set_ray_count.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.orc_set_noise.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.orc_set_skybox.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.orc_accum_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -73,6 +74,10 @@ class Oracle:
 
     def set_bounce_limit(self, n):
         self.L.orc_set_bounce_limit(self.h, int(n))
+
+    def set_ray_count(self, n):
+        """RAY_COUNT of the shader (Fragment.glsl:5): rays per pixel and frame."""
+        self.L.orc_set_ray_count(self.h, int(n))
 
     def set_noise(self, rgb):
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

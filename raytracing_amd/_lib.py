@@ -55,6 +55,7 @@ SIGNATURES = {
     "rt_set_materials": (I, [P, P, U32]),
     "rt_set_camera": (I, [P, ctypes.POINTER(rt_camera)]),
     "rt_set_bounce_limit": (I, [P, U32]),
+    "rt_set_ray_count": (I, [P, U32]),
     "rt_set_noise": (I, [P, P, U32, U32]),
     "rt_set_skybox": (I, [P, ctypes.POINTER(P), U32]),
     "rt_accum_clear": (I, [P]),

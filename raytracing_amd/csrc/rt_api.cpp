@@ -18,7 +18,8 @@
 
 namespace rtd {
 void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames, const FrameParams* single, uint32_t* queueHeads);
-void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
+void LaunchPrepareRays(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames, uint32_t rayCount);
+void LaunchTrace(bool count, bool ids, bool multi, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
                  void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
                  const uint32_t* order, uint32_t* tileCost);
 void LaunchOrderKeys(hipStream_t st, uint32_t* tileCost, uint32_t* keys, uint32_t* vals, uint32_t nTiles);
@@ -84,6 +85,7 @@ struct rt_context {
     bool haveNoise = false, haveSky = false, haveScene = false;
     bool countAll = false;
     uint64_t hostPaths = 0;          // pixel samples rendered while full counting was off
+    uint32_t rayCount = 1;           // RAY_COUNT, Fragment.glsl:5: rays traced and averaged per pixel and frame
     // kernel timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pendingEvents, freeEvents;
     double kernelMs = 0.0; uint64_t kernelLaunches = 0;
@@ -411,6 +413,13 @@ int rt_set_bounce_limit(rt_context* c, uint32_t bl) {
     return RT_OK;
 }
 
+int rt_set_ray_count(rt_context* c, uint32_t rays) {
+    if (!c) return RT_ERR_INVALID;
+    if (rays < 1u || rays > RT_MAX_RAY_COUNT) return Fail(c, RT_ERR_INVALID, "rt_set_ray_count: %u is outside 1..%u", rays, (unsigned)RT_MAX_RAY_COUNT);
+    c->rayCount = rays;
+    return RT_OK;
+}
+
 int rt_set_noise(rt_context* c, const uint8_t* rgb, uint32_t w, uint32_t h) try {
     if (!c) return RT_ERR_INVALID;
     if (!rgb || w == 0 || h == 0 || w > 16384 || h > 16384) return Fail(c, RT_ERR_INVALID, "rt_set_noise: bad texture");
@@ -487,7 +496,8 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
     // frame to frame. Only those launches tally rays per tile (one atomic per path, about 1.5 % of a launch).
     // A launch that alone comes near the fold threshold starts from empty columns; with the full counters on, one
     // that would exceed it eight times over is refused rather than allowed to wrap.
-    const uint64_t launchTileFrames = (uint64_t)nFrames * ((nGroups + nWaves - 1u) / nWaves);
+    // (a frame of R rays per pixel fills the counters like R frames)
+    const uint64_t launchTileFrames = (uint64_t)nFrames * (ids ? 1u : c->rayCount) * ((nGroups + nWaves - 1u) / nWaves);
     if (!ids && count && launchTileFrames > 8u * kFoldTileFrames)
         return Fail(c, RT_ERR_UNSUPPORTED, "rt_render: %u frames in one launch are too many for the 32-bit per-wave counters of counting mode; split the launch", nFrames);
     if (!ids && c->tileFramesSinceReduce != 0 && c->tileFramesSinceReduce + launchTileFrames >= kFoldTileFrames) {
@@ -499,7 +509,7 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
     const uint64_t k = ids ? 0 : c->launchesSinceAlloc + 1;
     const bool reorderAfter = !ids && ((k & (k - 1)) == 0 || (k & 7u) == 0);
     const uint32_t* order = (c->orderValid && !ids) ? c->dOrderVals + c->sp.shardTiles : nullptr;
-    LaunchTrace(count, ids, c->stream, nWaves, c->sp, c->dFrames, nFrames, c->dAccum, c->dTally, c->maxWaves, c->dIds, c->dSpill, c->dQueue, nGroups,
+    LaunchTrace(count, ids, !ids && c->rayCount > 1u, c->stream, nWaves, c->sp, c->dFrames, nFrames, c->dAccum, c->dTally, c->maxWaves, c->dIds, c->dSpill, c->dQueue, nGroups,
                 order, reorderAfter ? c->dTileCost : nullptr);
     HIP_TRY(c, hipGetLastError());
     if (!ids) {
@@ -512,7 +522,7 @@ static int LaunchShard(rt_context* c, bool count, bool ids, uint32_t nFrames) {
         // tile-frames per wave, whichever comes first, leaves three orders of magnitude of headroom at 2000 box tests
         // per path even if one wave takes eight times its share of the tiles.
         c->launchesSinceReduce += 1u;
-        c->tileFramesSinceReduce += (uint64_t)nFrames * ((nGroups + nWaves - 1u) / nWaves);
+        c->tileFramesSinceReduce += launchTileFrames;
         if (c->launchesSinceReduce >= 16u || c->tileFramesSinceReduce >= kFoldTileFrames) {
             LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);
             HIP_TRY(c, hipGetLastError());
@@ -552,20 +562,25 @@ static FrameParams MakeFrame(const rt_context* c, uint32_t index, const float* s
 // fills in their jitter and clears the tile queue heads. One frame: the record is an argument of that kernel.
 // Several frames: the records go through a pinned staging slot and one asynchronous copy; the host only waits when
 // all staging slots still have their copy queued, i.e. when it is four multi-frame launches ahead of the device.
-static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* seeds3) {
-    if (n == 1 && c->framesCap >= 1) {
-        const FrameParams f = MakeFrame(c, first, seeds3);
-        LaunchPrepareFrames(c->stream, c->sp, c->dFrames, 1, &f, c->dQueue);
-        HIP_TRY(c, hipGetLastError());
-        return RT_OK;
-    }
-    if (n > c->framesCap) {
+// With more than one ray per pixel and frame (`rays`), one record holding the ray count and a table of rays x n pixel
+// jitters (8 bytes each) follow the n frame records; prepare_rays_kernel fills both in.
+static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* seeds3, uint32_t rays) {
+    const uint64_t records = rays > 1u ? (uint64_t)n + 1u + ((uint64_t)n * rays * 8u + sizeof(FrameParams) - 1u) / sizeof(FrameParams) : n;
+    if (records > 0x7fffffffull / sizeof(FrameParams)) return Fail(c, RT_ERR_UNSUPPORTED, "rt_render: %u frames of %u rays are too many for one launch", n, rays);
+    if (records > c->framesCap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->dFrames) (void)hipFree(c->dFrames);
         c->dFrames = nullptr; c->framesCap = 0;
-        const uint32_t cap = std::max<uint32_t>(n, 64u);
+        const uint32_t cap = std::max<uint32_t>((uint32_t)records, 64u);
         HIP_TRY(c, hipMalloc((void**)&c->dFrames, sizeof(FrameParams) * cap));
         c->framesCap = cap;
+    }
+    if (n == 1) {
+        const FrameParams f = MakeFrame(c, first, seeds3);
+        LaunchPrepareFrames(c->stream, c->sp, c->dFrames, 1, &f, c->dQueue);
+        HIP_TRY(c, hipGetLastError());
+        if (rays > 1u) { LaunchPrepareRays(c->stream, c->sp, c->dFrames, 1, rays); HIP_TRY(c, hipGetLastError()); }
+        return RT_OK;
     }
     rt_context::FrameStage& sg = c->stage[c->stageNext++ % 4u];
     if (sg.pending) { HIP_TRY(c, hipEventSynchronize(sg.copied)); sg.pending = false; }
@@ -583,6 +598,7 @@ static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* 
     sg.pending = true;
     LaunchPrepareFrames(c->stream, c->sp, c->dFrames, n, nullptr, c->dQueue);
     HIP_TRY(c, hipGetLastError());
+    if (rays > 1u) { LaunchPrepareRays(c->stream, c->sp, c->dFrames, n, rays); HIP_TRY(c, hipGetLastError()); }
     return RT_OK;
 }
 
@@ -593,7 +609,7 @@ int rt_render(rt_context* c, uint32_t firstFrameIndex, uint32_t nFrames, const f
     int rc = CheckRenderable(c, "rt_render");
     if (rc != RT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = UploadFrames(c, firstFrameIndex, nFrames, seeds3);
+    rc = UploadFrames(c, firstFrameIndex, nFrames, seeds3, c->rayCount);
     if (rc != RT_OK) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!c->freeEvents.empty()) { ev = c->freeEvents.back(); c->freeEvents.pop_back(); }
@@ -603,7 +619,7 @@ int rt_render(rt_context* c, uint32_t firstFrameIndex, uint32_t nFrames, const f
     if (rc != RT_OK) return rc;
     HIP_TRY(c, hipEventRecord(ev.second, c->stream));
     c->pendingEvents.push_back(ev);
-    if (!c->countAll) c->hostPaths += c->shardPixels * nFrames;
+    if (!c->countAll && c->rayCount == 1u) c->hostPaths += c->shardPixels * nFrames;      // (with several rays per pixel the kernel counts its paths)
     if (c->pendingEvents.size() > 256) { rc = ResolveEvents(c); if (rc != RT_OK) return rc; }
     return RT_OK;
 }
@@ -621,7 +637,7 @@ int rt_primary_ids(rt_context* c, const float* seed3, int32_t* out3) try {
     int rc = CheckRenderable(c, "rt_primary_ids");
     if (rc != RT_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = UploadFrames(c, 0, 1, seed3);
+    rc = UploadFrames(c, 0, 1, seed3, 1u);
     if (rc != RT_OK) return rc;
     // what rt_render has tallied so far goes to the totals first: the id pass shares the tally columns
     LaunchReduceTally(c->stream, c->dTally, c->maxWaves, c->dTotals, kCounterSlots);

@@ -324,6 +324,13 @@ struct Lane {
     float bestT; int bestIdx;
     int iters;              // iterationsCount
 };
+// The loop over RAY_COUNT rays of one pixel and frame (F:453-485), carried by a lane next to its Lane in kernels built for
+// more than one ray.
+struct PixelRays {
+    uint32_t sample;        // i of that loop
+    uint32_t did;           // iterationsDid
+    V3 sum;                 // rgb
+};
 
 typedef uint32_t Words4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) Words4 LdsWords4;
@@ -524,10 +531,26 @@ __global__ void prepare_frames_kernel(SceneParams sp, FrameParams* __restrict__ 
     frames[k] = f;
 }
 
+// More than one ray per pixel and frame (the shader's compile-time RAY_COUNT, F:5,459-483): behind the nFrames frame
+// records lies one record whose first word is the ray count R, and behind that the pixel jitter of ray i of frame k as
+// float2 [k * R + i]: F:461 looks it up at u_RandSeed.yz + 0.007 * i, which depends on the frame and on i only. Runs after
+// prepare_frames_kernel, on the same stream.
+__global__ void prepare_rays_kernel(SceneParams sp, FrameParams* __restrict__ frames, uint32_t nFrames, uint32_t rayCount) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0u) reinterpret_cast<uint32_t*>(frames + nFrames)[0] = rayCount;
+    if (j >= nFrames * rayCount) return;
+    const uint32_t k = j / rayCount, i = j - k * rayCount;
+    const FrameParams f = frames[k];
+    const float off = 0.007f * (float)i;
+    V3 ro = sample_noise(sp, f.seedY + off, f.seedZ + off);
+    reinterpret_cast<float2*>(frames + nFrames + 1)[j] = make_float2(ro.x, ro.y);
+}
+
 // COUNT: full tallies; IDS: primary-hit ids instead of radiance (one frame); SINGLE: the launch
 // renders one frame, whose parameters then live in scalar registers; ITERS: the shader's iterationsCount is
-// kept (needed by the tallies, the id pass and the heat-map view of bounce limit 0 only).
-template <bool COUNT, bool IDS, bool SINGLE, bool ITERS>
+// kept (needed by the tallies, the id pass and the heat-map view of bounce limit 0 only); MULTI: several rays per pixel
+// and frame (the ray count and the jitter table lie behind the frame records, see prepare_rays_kernel).
+template <bool COUNT, bool IDS, bool SINGLE, bool ITERS, bool MULTI>
 __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(SceneParams sp, const FrameParams* __restrict__ frames, uint32_t nFrames,
                                                    float4* __restrict__ accum, uint32_t* __restrict__ tally /* [slots][tallyStride] */,
                                                    int32_t* __restrict__ ids /* IDS only: [slot][3] */,
@@ -574,6 +597,8 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
     const uint32_t nTiles = sp.tilesX * sp.tilesY;
     FrameParams f0 = {};
     if (SINGLE) f0 = frames[0];
+    const uint32_t rayCount = MULTI ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t*>(frames + nFrames)[0]) : 1u;
+    const float2* rayJitter = reinterpret_cast<const float2*>(frames + nFrames + 1);      // MULTI only
 
     // Tiles are queued in 8 bands of consecutive positions of the hand-out order (with the order the host
     // builds, a band is a contiguous eighth of the shard, most expensive tiles first); a wave drains the band
@@ -592,6 +617,7 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
     L.previous = mk(0.f, 0.f, 0.f); L.throughput = mk(1.f, 1.f, 1.f);
     L.ray.o = L.ray.d = L.ray.inv = mk(0.f, 0.f, 0.f);
     V3 hitNormal = mk(0.0f, 0.0f, 0.0f);      // hitRecord.normal persists across bounces of a path (F:381)
+    PixelRays P = {0u, 0u, mk(0.f, 0.f, 0.f)};
 
     for (;;) {
         // ---- pick what to run: the most populated of interior / leaf / feed (ballot + popcount, wave-uniform).
@@ -684,6 +710,10 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                     }
                     uint32_t sx = Hashf(L.ray.o.x + L.ray.d.y) + hi + fp.hashX;
                     uint32_t sy = Hashf(L.ray.o.y + L.ray.d.z) + hj + fp.hashY;
+                    if (MULTI) {                 // Hash(iRayCountSeed): the frame records hold the term of ray 0
+                        const uint32_t d = Hash(P.sample) - Hash(0u);
+                        sx += d; sy += d;
+                    }
                     float fsx = (float)sx, fsy = (float)sy;
                     float seedx = div_by_uniform(fsx - nresx * floorf(div_by_uniform(fsx, nresx, rnresx)), nresx, rnresx);
                     float seedy = div_by_uniform(fsy - nresy * floorf(div_by_uniform(fsy, nresy, rnresy)), nresy, rnresy);
@@ -762,14 +792,38 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                     }
                 }
                 if (done) {
-                    // F:480-487
-                    V3 rgb = mk(0.0f, 0.0f, 0.0f) + result;
-                    rgb = rgb * (1.0f / 1.0f);
-                    L.previous = mix3(L.previous, rgb, fp.weight);
-                    if (COUNT) tl.paths++;
+                    bool frameDone = true;
+                    V3 rgb;
+                    if (MULTI) {
+                        // F:467-483: the loop over the pixel's rays skips up to three of them when a ray's colour is close
+                        // to the sum of those before it
+                        const V3 diff = abs3(P.sum - result);
+                        const float distance = (diff.x + diff.y) + diff.z;
+                        uint32_t i = P.sample;
+                        if (i > 0u) {
+                            if (distance < 0.5f) i += 1u;
+                            if (distance < 0.2f) i += 1u;
+                            if (distance < 0.1f) i += 1u;
+                        }
+                        P.sum = P.sum + result;
+                        P.did += 1u;
+                        i += 1u;
+                        P.sample = i;
+                        frameDone = !(i < rayCount);
+                        rgb = P.sum * (1.0f / (float)P.did);                         // F:484-485
+                    } else {
+                        // F:480-487
+                        rgb = mk(0.0f, 0.0f, 0.0f) + result;
+                        rgb = rgb * (1.0f / 1.0f);
+                    }
+                    if (frameDone) L.previous = mix3(L.previous, rgb, fp.weight);
+                    if (COUNT || MULTI) tl.paths++;
                     // what this path cost, for the next launches' hand-out order (no value returned: fire and forget)
                     if (tileCost) __hip_atomic_fetch_add(&tileCost[L.slot >> 6], L.segments + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ++L.k;
+                    if (frameDone) {
+                        if (MULTI) { P.sample = 0u; P.did = 0u; P.sum = mk(0.0f, 0.0f, 0.0f); }
+                        ++L.k;
+                    }
                     if (L.k >= nFrames) {
                         accum[L.slot] = make_float4(L.previous.x, L.previous.y, L.previous.z, 0.0f);
                         L.state = kIdle;
@@ -812,6 +866,7 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                         const uint32_t px = tileX * kTile + (inTile & 7u), py = tileY * kTile + (inTile >> 3);
                         if (tile < nTiles && px < sp.width && py < sp.height) {
                             L.slot = s; L.k = 0;
+                            if (MULTI) { P.sample = 0u; P.did = 0u; P.sum = mk(0.0f, 0.0f, 0.0f); }
                             float4 acc = IDS ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[s];
                             L.previous = mk(acc.x, acc.y, acc.z);
                             L.state = kNewPath;
@@ -825,7 +880,8 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
             if (COUNT) { tl.rounds[0] += (lane == 0); tl.lanes[0] += (L.state == kNewPath); }
             if (L.state == kNewPath) {
                 float jx, jy;
-                if (SINGLE) { jx = f0.jitterX; jy = f0.jitterY; } else { jx = frames[L.k].jitterX; jy = frames[L.k].jitterY; }
+                if (MULTI) { const float2 j = rayJitter[mul24(L.k, rayCount) + P.sample]; jx = j.x; jy = j.y; }
+                else if (SINGLE) { jx = f0.jitterX; jy = f0.jitterY; } else { jx = frames[L.k].jitterX; jy = frames[L.k].jitterY; }
                 const uint32_t tile = (L.slot >> 6) * sp.shardWorld + sp.shardRank, inTile = L.slot & 63u;
                 uint32_t tileX, tileY;
                 divmod_uniform(tile, sp.tilesX, rTilesX, tileY, tileX);
@@ -850,7 +906,7 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                                     lane == 0 ? (uint32_t)(rc.cycles[0] >> 6) : 0u, lane == 0 ? (uint32_t)(rc.cycles[1] >> 6) : 0u,
                                     lane == 0 ? (uint32_t)(rc.cycles[2] >> 6) : 0u, lane == 0 ? (uint32_t)(rc.cycles[3] >> 6) : 0u};
     for (int s = 0; s < (int)kCounterSlots; ++s) {
-        if (!COUNT && s != (int)kRays) continue;
+        if (!COUNT && s != (int)kRays && !(MULTI && s == (int)kPaths)) continue;      // (with several rays per pixel the host cannot count paths itself)
         uint32_t v = vals[s];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) tally[(size_t)s * tallyStride + wave] += v;
@@ -935,7 +991,7 @@ uint32_t ResidentWaves() {
     int dev = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false, true, false>, 64 * kWgWaves, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, trace_kernel<false, false, true, false, false>, 64 * kWgWaves, 0) != hipSuccess) return 0;
     if (perCu < 1) perCu = 1;
     return (uint32_t)cus * (uint32_t)perCu * (uint32_t)kWgWaves;
 }
@@ -945,7 +1001,14 @@ void LaunchPrepareFrames(hipStream_t st, const SceneParams& sp, FrameParams* fra
                        single ? 1 : 0, queueHeads);
 }
 
-void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
+void LaunchPrepareRays(hipStream_t st, const SceneParams& sp, FrameParams* frames, uint32_t nFrames, uint32_t rayCount) {
+    const uint32_t n = nFrames * rayCount;
+    hipLaunchKernelGGL(prepare_rays_kernel, dim3((n + 63u) / 64u), dim3(64), 0, st, sp, frames, nFrames, rayCount);
+}
+
+// multi: more than one ray per pixel and frame; `frames` then carries the ray count and the jitter table behind its
+// nFrames records (LaunchPrepareRays).
+void LaunchTrace(bool count, bool ids, bool multi, hipStream_t st, uint32_t nWaves, const SceneParams& sp, const FrameParams* frames, uint32_t nFrames,
                  void* accum, uint32_t* tally, uint32_t tallyStride, int32_t* idsOut, void* spillArea, uint32_t* queueHeads, uint32_t nGroups,
                  const uint32_t* order, uint32_t* tileCost) {
     float4* a = static_cast<float4*>(accum);
@@ -953,14 +1016,20 @@ void LaunchTrace(bool count, bool ids, hipStream_t st, uint32_t nWaves, const Sc
     dim3 grid((nWaves + (uint32_t)kWgWaves - 1u) / (uint32_t)kWgWaves), block(64 * kWgWaves);     // the per-wave arrays hold a multiple of kWgWaves
     const bool single = nFrames == 1u;
     const bool heat = sp.bounceLimit == 0u;        // the only view that shows iterationsCount
-#define RT_LAUNCH(C, I, S, T) hipLaunchKernelGGL((trace_kernel<C, I, S, T>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost)
-    if (ids) RT_LAUNCH(true, true, true, true);
-    else if (count && single) RT_LAUNCH(true, false, true, true);
-    else if (count) RT_LAUNCH(true, false, false, true);
-    else if (single && heat) RT_LAUNCH(false, false, true, true);
-    else if (single) RT_LAUNCH(false, false, true, false);
-    else if (heat) RT_LAUNCH(false, false, false, true);
-    else RT_LAUNCH(false, false, false, false);
+#define RT_LAUNCH(C, I, S, T, M) hipLaunchKernelGGL((trace_kernel<C, I, S, T, M>), grid, block, 0, st, sp, frames, nFrames, a, tally, idsOut, sa, queueHeads, nGroups, tallyStride, order, tileCost)
+    if (ids) RT_LAUNCH(true, true, true, true, false);
+    else if (multi) {
+        if (count && single) RT_LAUNCH(true, false, true, true, true);
+        else if (count) RT_LAUNCH(true, false, false, true, true);
+        else if (single) RT_LAUNCH(false, false, true, true, true);       // (the views that show iterationsCount included)
+        else RT_LAUNCH(false, false, false, true, true);
+    }
+    else if (count && single) RT_LAUNCH(true, false, true, true, false);
+    else if (count) RT_LAUNCH(true, false, false, true, false);
+    else if (single && heat) RT_LAUNCH(false, false, true, true, false);
+    else if (single) RT_LAUNCH(false, false, true, false, false);
+    else if (heat) RT_LAUNCH(false, false, false, true, false);
+    else RT_LAUNCH(false, false, false, false, false);
 #undef RT_LAUNCH
 }
 

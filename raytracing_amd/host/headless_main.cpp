@@ -5,7 +5,8 @@
 //   raytracer_headless [--ini RayTracer.ini] [--noise ./Textures/Noise/rgbNoise.png]
 //                      [--width 1280 --height 720] [--frames 64] [--device 0] [--threads 8]
 //                      [--keys "K4 W+ 10 W- 50"] [--poses file --spp 256] [--out shots] [--no-bloom] [--flip]
-//                      [--offline [--rank r --world n]] [--cache dir]
+//                      [--offline [--rank r --world n]] [--cache dir] [--ray-count 1]
+// --ray-count N: the shader's compile-time RAY_COUNT (src/shaders/Fragment.glsl:5), rays per pixel and frame; 1 as checked in.
 // --gpus N: one image on GPUs 0..N-1 of this process (tile sharding, shards gathered over RCCL: rt_group_*); renders
 // --frames frames from the default camera (no key replay, no poses) and writes <out>.png. The bloom chain runs once, on the
 // gathered image; the plain loop runs it for every displayed frame and carries its tmp texture over as the reference does,
@@ -42,7 +43,7 @@ static int Die(const char* what, rt_context* ctx = nullptr) {
 // shards are gathered to the root context (RCCL) for the bloom chain and the PNG.
 static int RenderOnGroup(uint32_t gpus, uint32_t width, uint32_t height, uint32_t frames, int threads, const std::string& skyDir,
                          const std::string& noisePath, const std::vector<std::string>& objects, const std::string& cacheDir,
-                         const std::string& outDir, bool bloom, bool flip) {
+                         const std::string& outDir, bool bloom, bool flip, uint32_t rayCount) {
     std::vector<int> devices(gpus);
     for (uint32_t i = 0; i < gpus; ++i) devices[i] = (int)i;
     rt_group* group = nullptr;
@@ -71,7 +72,8 @@ static int RenderOnGroup(uint32_t gpus, uint32_t width, uint32_t height, uint32_
         rt_context* c = rt_group_rank(group, r);
         if (rt_set_skybox(c, facePtr, faces[0].width) != RT_OK || rt_set_noise(c, noise.pixels.data(), noise.width, noise.height) != RT_OK ||
             rt_scene_upload(c, scene.tri12.data(), scene.matIdx.data(), scene.TriangleCount(), scene.node8.data(), scene.NodeCount()) != RT_OK ||
-            rt_set_materials(c, mats.data(), (uint32_t)mats.size()) != RT_OK || rt_set_camera(c, &cam) != RT_OK || rt_set_bounce_limit(c, 4) != RT_OK)
+            rt_set_materials(c, mats.data(), (uint32_t)mats.size()) != RT_OK || rt_set_camera(c, &cam) != RT_OK || rt_set_bounce_limit(c, 4) != RT_OK ||
+            rt_set_ray_count(c, rayCount) != RT_OK)
             return Die("setting up a rank", c);
     }
     std::printf("triangles count: %u\n%u GPUs\n", scene.TriangleCount(), gpus);
@@ -97,7 +99,7 @@ int main(int argc, char** argv) {
     std::string ini = "RayTracer.ini", noisePath = "./Textures/Noise/rgbNoise.png", keys, poses, outDir = "shots", cacheDir;
     uint32_t width = 1280, height = 720, frames = 64, spp = 256;   // window size of src/main.cpp:28-29
     int device = 0, threads = 8;
-    uint32_t rank = 0, world = 1, gpus = 0;
+    uint32_t rank = 0, world = 1, gpus = 0, rayCount = 1;
     bool bloom = true, flip = false, offline = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -108,6 +110,7 @@ int main(int argc, char** argv) {
         else if (a == "--keys") keys = next(); else if (a == "--poses") poses = next(); else if (a == "--spp") spp = std::atoi(next());
         else if (a == "--out") outDir = next(); else if (a == "--no-bloom") bloom = false; else if (a == "--flip") flip = true;
         else if (a == "--cache") cacheDir = next(); else if (a == "--gpus") gpus = std::atoi(next());
+        else if (a == "--ray-count") rayCount = std::atoi(next());
         else if (a == "--offline") offline = true; else if (a == "--rank") rank = std::atoi(next()); else if (a == "--world") world = std::atoi(next());
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -118,10 +121,11 @@ int main(int argc, char** argv) {
 
     if (gpus > 0) {
         if (!keys.empty() || !poses.empty()) { std::fprintf(stderr, "--gpus renders a fixed camera: not with --keys or --poses\n"); return 2; }
-        return RenderOnGroup(gpus, width, height, frames, threads, skyDir, noisePath, objects, cacheDir, outDir, bloom, flip);
+        return RenderOnGroup(gpus, width, height, frames, threads, skyDir, noisePath, objects, cacheDir, outDir, bloom, flip, rayCount);
     }
     rt_context* ctx = nullptr;
     if (rt_create(device, width, height, &ctx) != RT_OK) { std::fprintf(stderr, "error: %s\n", rt_last_global_error()); return 1; }
+    if (rt_set_ray_count(ctx, rayCount) != RT_OK) return Die("--ray-count", ctx);
 
     // sky box: right, left, top, bottom, front, back -> +X,-X,+Y,-Y,+Z,-Z (src/main.cpp:52-70)
     static const char* kFaces[6] = {"right.png", "left.png", "top.png", "bottom.png", "front.png", "back.png"};

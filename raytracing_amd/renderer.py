@@ -153,6 +153,10 @@ class Renderer:
     def set_bounce_limit(self, n):
         self._ck(self.L.rt_set_bounce_limit(self.h, int(n)), "rt_set_bounce_limit")
 
+    def set_ray_count(self, n):
+        """Rays per pixel and frame: the shader's compile-time RAY_COUNT (Fragment.glsl:5), 1 in the reference as checked in."""
+        self._ck(self.L.rt_set_ray_count(self.h, int(n)), "rt_set_ray_count")
+
     def set_noise(self, rgb):
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         assert rgb.ndim == 3 and rgb.shape[2] == 3

@@ -390,6 +390,20 @@ def test_offline_video_path_matches_tracer_and_post_oracle(tmp_path):
     test_video_gpu.test_every_pose_matches_tracer_and_post_oracle(tmp_path)
 
 
+import test_zy_ray_count_gpu
+
+
+@pytest.mark.parametrize("path", test_zy_ray_count_gpu.RAY_FIXTURES, ids=[p.split("raycount_")[-1][:-4] for p in test_zy_ray_count_gpu.RAY_FIXTURES])
+def test_kernels_reproduce_the_llvmpipe_fixtures_with_several_rays_per_pixel(path):
+    """The shader's RAY_COUNT above 1 (rt_set_ray_count): what llvmpipe rendered with the reference's constant changed."""
+    test_zy_ray_count_gpu.test_reproduces_reference_fixture(path)
+
+
+def test_several_rays_per_pixel_counters_shards_and_long_launches():
+    test_zy_ray_count_gpu.test_counters_shards_and_return_to_one_ray()
+    test_zy_ray_count_gpu.test_many_frames_of_many_rays_in_one_launch()
+
+
 @pytest.mark.parametrize("cus,threads", [(1, 1), (3, 2), (40, 4)])
 def test_any_grid_size_gives_the_same_image(cus, threads):
     """The persistent grid is sized to the machine: one work-group that takes every tile, a few, and far more waves than

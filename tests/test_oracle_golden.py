@@ -80,6 +80,37 @@ def test_progressive_radiance(fx):
     assert n >= 1
 
 
+RAY_FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "raycount_*.npz")))
+
+
+def ray_count_cases(fx):
+    for k in fx.files:
+        if k.startswith("radiance_r"):
+            r, rest = k[len("radiance_r"):].split("_b")
+            b, f = rest.split("_f")
+            yield k, int(r), int(b), int(f)
+
+
+@pytest.mark.parametrize("path", RAY_FIXTURES, ids=[os.path.basename(f)[9:-4] for f in RAY_FIXTURES])
+def test_several_rays_per_pixel(path):
+    """RAY_COUNT above 1 (Fragment.glsl:5,459-485): fixtures rendered by the reference's shader on llvmpipe with its own
+    compile-time constant set to 2..6. Bit-exact, the two debug views included."""
+    fx = np.load(path)
+    W, H = int(fx["width"]), int(fx["height"])
+    o = Oracle(W, H)
+    load_into(o, fx)
+    n = 0
+    for key, rays, bl, frames in ray_count_cases(fx):
+        o.clear()
+        o.set_ray_count(rays)
+        o.set_bounce_limit(bl)
+        o.render(0, fx["seeds"][:frames])
+        got = o.read_accum()[..., :3]
+        assert (bits(got) == bits(fx[key])).all(), key
+        n += 1
+    assert n >= 1 and len(RAY_FIXTURES) >= 3
+
+
 def test_texture_filters_match_llvmpipe():
     t = np.load(os.path.join(GOLDEN, "texture_filter.npz"))
     o = Oracle(8, 8)

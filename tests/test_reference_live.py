@@ -37,6 +37,26 @@ def test_restatement_equals_live_shader(case):
     assert run.stdout.count("pixels differ") == frames
 
 
+RAY_CASES = [
+    # scene, triangles, width, height, bounce limit, frames, RAY_COUNT
+    ("lightbox", 0, 120, 72, 4, 3, 2),
+    ("sponza_like", 9000, 110, 64, 8, 2, 5),
+    ("dragon_like", 7000, 96, 60, 16, 2, 3),
+]
+
+
+@pytest.mark.parametrize("case", RAY_CASES, ids=["%s-rays%d" % (c[0], c[6]) for c in RAY_CASES])
+def test_restatement_equals_live_shader_with_several_rays_per_pixel(case):
+    """The shader's loop over RAY_COUNT rays per pixel (Fragment.glsl:459-485), with the reference's own compile-time
+    constant set to 2, 3 and 5 while its file is loaded: per-ray jitter, per-ray seed term, the early-out and the mean."""
+    scene, tris, w, h, bounces, frames, rays = case
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "compare_reference.py"), "--scene", scene, "--tris", str(tris), "--width", str(w),
+           "--height", str(h), "--bounces", str(bounces), "--frames", str(frames), "--skip-seeds", "3", "--ray-count", str(rays)]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert run.stdout.count("pixels differ") == frames
+
+
 POST_LIVE = r'''
 import sys
 import numpy as np
