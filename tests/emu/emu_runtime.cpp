@@ -13,6 +13,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -238,17 +240,78 @@ hipError_t hipSetDevice(int d) { if (d < 0 || d >= DeviceCount()) return hipErro
 hipError_t hipGetDevice(int* d) { *d = tlsDevice; return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t, int) { *value = (int)EnvNumber("RT_EMU_CUS", 2); return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
+// ---- the table of "device" allocations: lets the assembly interpreter (tests/emu/isa) tell a valid access from a stray one ----
+namespace {
+std::mutex gRangesLock;
+std::map<uintptr_t, size_t> gRanges;
+bool Known(uintptr_t a, size_t bytes) {
+    auto it = gRanges.upper_bound(a);
+    if (it == gRanges.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->first + it->second;
+}
+}  // namespace
 hipError_t emu_malloc(void** p, size_t bytes) {
     *p = nullptr;
     if (bytes == 0) bytes = 1;
     void* q = nullptr;
     if (posix_memalign(&q, 256, bytes) != 0) return hipErrorOutOfMemory;
     memset(q, 0xA5, bytes);       // device memory arrives uninitialised: make reliance on zeros visible
+    { std::lock_guard<std::mutex> g(gRangesLock); gRanges[(uintptr_t)q] = bytes; }
     *p = q;
     return hipSuccess;
 }
-hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipFree(void* p) { if (p) { std::lock_guard<std::mutex> g(gRangesLock); gRanges.erase((uintptr_t)p); } free(p); return hipSuccess; }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
+
+// ---- for tests/emu/isa: the launch hook and lane-wide memory access with every address checked against the table ----
+namespace { int (*gLaunchHook)(const char*, const unsigned*, const unsigned char*, size_t) = nullptr; }
+namespace emu {
+bool OfferLaunch(const char* kernel, dim3 grid, dim3 block, const unsigned char* args, size_t bytes) {
+    if (!gLaunchHook) return false;
+    const unsigned dims[6] = {grid.x, grid.y, grid.z, block.x, block.y, block.z};
+    return gLaunchHook(kernel, dims, args, bytes) != 0;
+}
+}  // namespace emu
+extern "C" {
+void emu_set_launch_hook(int (*hook)(const char*, const unsigned*, const unsigned char*, size_t)) { gLaunchHook = hook; }
+void emu_register_range(const void* p, size_t bytes) { std::lock_guard<std::mutex> g(gRangesLock); gRanges[(uintptr_t)p] = bytes; }
+void emu_forget_range(const void* p) { std::lock_guard<std::mutex> g(gRangesLock); gRanges.erase((uintptr_t)p); }
+// out[d * 64 + lane] = dword d at addr[lane], for the lanes in mask; returns the lanes whose address is no allocation's
+uint64_t emu_gather(const uint64_t* addr, uint64_t mask, int ndw, uint32_t* out) {
+    uint64_t bad = 0;
+    std::lock_guard<std::mutex> g(gRangesLock);
+    for (int l = 0; l < 64; ++l) {
+        if (!(mask >> l & 1u)) continue;
+        if ((addr[l] & 3u) || !Known((uintptr_t)addr[l], (size_t)ndw * 4)) { bad |= 1ull << l; continue; }
+        for (int d = 0; d < ndw; ++d) out[d * 64 + l] = ((const uint32_t*)addr[l])[d];
+    }
+    return bad;
+}
+uint64_t emu_scatter(const uint64_t* addr, uint64_t mask, int ndw, const uint32_t* in) {
+    uint64_t bad = 0;
+    std::lock_guard<std::mutex> g(gRangesLock);
+    for (int l = 0; l < 64; ++l) {
+        if (!(mask >> l & 1u)) continue;
+        if ((addr[l] & 3u) || !Known((uintptr_t)addr[l], (size_t)ndw * 4)) { bad |= 1ull << l; continue; }
+        for (int d = 0; d < ndw; ++d) ((uint32_t*)addr[l])[d] = in[d * 64 + l];
+    }
+    return bad;
+}
+uint64_t emu_atomic_add_u32(const uint64_t* addr, uint64_t mask, const uint32_t* data, uint32_t* before) {
+    uint64_t bad = 0;
+    std::lock_guard<std::mutex> g(gRangesLock);
+    for (int l = 0; l < 64; ++l) {
+        if (!(mask >> l & 1u)) continue;
+        if ((addr[l] & 3u) || !Known((uintptr_t)addr[l], 4)) { bad |= 1ull << l; continue; }
+        before[l] = __atomic_fetch_add((uint32_t*)addr[l], data[l], __ATOMIC_RELAXED);
+    }
+    return bad;
+}
+int emu_known(const void* p, size_t bytes) { std::lock_guard<std::mutex> g(gRangesLock); return Known((uintptr_t)p, bytes) ? 1 : 0; }
+// out = fma(a, b, c) in single precision, one rounding
+void emu_vfma(const float* a, const float* b, const float* c, float* out, int n) { for (int i = 0; i < n; ++i) out[i] = fmaf(a[i], b[i], c[i]); }
+}
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemset(void* dst, int value, size_t bytes) { if (bytes) memset(dst, value, bytes); return hipSuccess; }

@@ -134,4 +134,24 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 static inline hipError_t hipGetSymbolAddress(void** p, const void* symbol) { *p = const_cast<void*>(symbol); return hipSuccess; }
 template <class F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 1; return hipSuccess; }
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::emu::Launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+// A launch first offers itself, by name and with its arguments laid out as the device's kernel-argument segment (each
+// argument at its natural alignment), to a hook a test may have installed (emu_set_launch_hook: tests/emu/isa runs the
+// compiler's gfx950 assembly of the kernel instead of its C++ source); without a hook, or when the hook declines, the
+// kernel's source runs on fibers as usual.
+namespace emu {
+template <class T> static inline void PackOne(unsigned char* buf, size_t& at, const T& v) {
+    at = (at + alignof(T) - 1) / alignof(T) * alignof(T);
+    memcpy(buf + at, &v, sizeof(T));
+    at += sizeof(T);
+}
+bool OfferLaunch(const char* kernel, dim3 grid, dim3 block, const unsigned char* args, size_t bytes);
+template <class... A> static inline bool Offer(const char* kernel, dim3 grid, dim3 block, const A&... a) {
+    alignas(16) unsigned char buf[1024];
+    memset(buf, 0, sizeof buf);
+    size_t at = 0;
+    (PackOne(buf, at, a), ...);
+    return OfferLaunch(kernel, grid, block, buf, at);
+}
+}  // namespace emu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    do { if (!::emu::Offer(#kernel, (grid), (block), __VA_ARGS__)) ::emu::Launch((grid), (block), [=]() { kernel(__VA_ARGS__); }); } while (0)

@@ -1,0 +1,143 @@
+"""The kernels as the compiler built them, on the CPU: hipcc's gfx950 assembly of trace_kernels.hip executed by an
+interpreter of the instructions it uses (tests/emu/isa), inside the host emulation of the library, against the oracle, bit
+for bit. The fiber emulation (tests/test_emulated.py) checks the kernels' source; this checks their machine code: the
+registers and flags a wave really has, EXEC-masked lock step, scalar/vector split, LDS and scratch addressing, and
+that every memory result is waited for before a register it lands in is named again. Registers, LDS and scratch start with
+random bits, global addresses are checked against the runtime's allocations. What it cannot see: timing, and hazards that
+need idle cycles rather than waits. Needs hipcc (no GPU): skipped where there is none."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import raytracing_amd as ra
+from emulation import Emulated
+from raytracing_amd import scenes
+from rt_oracle import Oracle
+from util import differing_pixels, make_scene, setup
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu", "isa"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc to produce the device assembly")
+
+NOISE = scenes.noise_texture(64, 48)
+SKY = scenes.sky_cubemap(32)
+SEEDS = scenes.frame_seeds(6)
+KERNELS = ("trace_kernel", "prepare_frames_kernel", "prepare_rays_kernel")
+
+
+@pytest.fixture(scope="module")
+def assembly():
+    from harness import assemble
+    return assemble()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emulated_module():
+    with Emulated(devices=1, cus=2):
+        yield
+
+
+def test_the_interpreter_notices_a_missing_wait(assembly):
+    """The wait checker on a kernel whose every third vector-memory wait is taken away: it must object."""
+    import gcn_interp as gi
+    from harness import FromAssembly
+    original = gi.Machine._check_wait
+
+    def lossy(self, w, pc):
+        ins = self.k.instrs[pc]
+        if ins.op == "s_waitcnt" and "lgkmcnt" not in ins.text and ins.line % 3 == 0:
+            return
+        return original(self, w, pc)
+    g = ra.Renderer(16, 8)
+    setup(g, make_scene("lightbox"), NOISE, SKY, bounce_limit=4)
+    gi.Machine._check_wait = lossy
+    try:
+        with FromAssembly(assembly, check_waits=True) as run:
+            g.render(0, SEEDS[:1]); run.check()
+            assert len(run.wait_violations()) > 100
+    finally:
+        gi.Machine._check_wait = original
+    with FromAssembly(assembly, check_waits=True) as run:
+        g.render(1, SEEDS[1:2]); run.check()
+        assert run.wait_violations() == []
+    g.close()
+
+
+@pytest.mark.parametrize("scene,kw,W,H", [("lightbox", {}, 16, 8), ("sponza_like", {"target_tris": 6000}, 19, 9)], ids=["lightbox", "sponza_like"])
+def test_machine_code_of_every_tracer_kernel_equals_the_oracle(assembly, scene, kw, W, H):
+    """All eleven instantiations: one frame / several frames per launch, the heat-map view, full counters, primary ids, and
+    the four kernels for several rays per pixel; the two kernels that prepare a launch run from their assembly too."""
+    from harness import FromAssembly
+    sc = make_scene(scene, **kw)
+    g, o = ra.Renderer(W, H), Oracle(W, H)
+    setup(g, sc, NOISE, SKY)
+    setup(o, sc, NOISE, SKY)
+    seen = set()
+    with FromAssembly(assembly, kernels=KERNELS, garbage=13, check_waits=True) as run:
+        #        rays, bounce limit, frames, full counters
+        cases = [(1, 4, 1, False), (1, 2, 2, False), (1, 0, 1, False), (1, 0, 2, False), (1, 4, 1, True), (1, 2, 2, True),
+                 (3, 4, 1, False), (2, 2, 2, False), (2, 4, 1, True), (2, 1, 2, True)]
+        if scene != "lightbox":          # the larger tree (node records from memory, not only from the LDS copy): four of the kernels
+            cases = [(1, 8, 1, False), (1, 2, 2, False), (3, 4, 1, False), (1, 4, 1, True)]
+        for rays, bl, frames, count in cases:
+            for r in (g, o):
+                r.set_ray_count(rays); r.set_bounce_limit(bl); r.clear(); r.counters(reset=True)
+            g.set_counting(count)
+            n0 = len(run.launches)
+            g.render(0, SEEDS[:frames]); run.check()
+            o.render(0, SEEDS[:frames])
+            assert differing_pixels(g.read_accum(), o.read_accum()) == 0, (rays, bl, frames, count)
+            cg, co = g.counters(reset=True), o.counters(reset=True)
+            for k in (co if count else ("rays",)):
+                assert cg[k] == co[k], (rays, bl, frames, count, k)
+            seen.update(l[0] for l in run.launches[n0:])
+            assert sum(l[3] for l in run.launches[n0:]) == 0      # no LDS access beyond the work-group's allocation
+        g.set_counting(False)
+        assert (g.primary_ids(SEEDS[0]) == o.primary_ids(SEEDS[0])).all(); run.check()
+        seen.add(run.launches[-1][0])
+        assert run.wait_violations() == []
+    assert len([s for s in seen if "trace_kernel" in s]) == (11 if scene == "lightbox" else 5), sorted(seen)
+    assert any("prepare_rays_kernel" in s for s in seen) and any("prepare_frames_kernel" in s for s in seen)
+    g.close()
+
+
+def test_a_stray_address_is_reported_not_followed(assembly):
+    """A triangle reference that points past the triangle array (a damaged record, written behind the library's back): the
+    interpreter names the load and the lanes instead of reading whatever lies there."""
+    import ctypes
+    import gcn_interp as gi
+    from harness import FromAssembly
+    W, H = 16, 8
+    g = ra.Renderer(W, H)
+    one = np.array([[4, -1, -1, 0, 4, 1, -1, 0, 4, 0, 1, 0]], dtype=np.float32)
+    node = np.array([[4, 1, 1, 4, -1, -1, 1, 0]], dtype=np.float32)
+    g.set_scene(one, np.zeros(1, np.int32), node)
+    g.set_materials(np.array([[0.8, 0.3, 0.2, 1, 1, 1, 1, 0, 0, 0, 0]], dtype=np.float32))
+    from util import DEFAULT_CAMERA
+    g.set_camera(**DEFAULT_CAMERA); g.set_noise(NOISE); g.set_skybox(SKY); g.set_bounce_limit(4)
+    with FromAssembly(assembly) as run:
+        g.render(0, SEEDS[:1]); run.check()                  # the intact scene renders
+        # the scene is a single leaf, referenced by the launch's scene parameters: make the next launch's copy claim the
+        # triangle 2^20 records further on
+        L = run.lib
+        original = run._hook
+
+        def damaged(name, dims, args, nbytes):
+            if b"trace_kernel" in name:
+                raw = bytearray(args[:nbytes])
+                words = np.frombuffer(raw, np.uint32)
+                hits = np.nonzero(words == np.uint32(0x80000000))[0]          # leaf bit | count 1 | first triangle 0
+                assert len(hits) == 1
+                words = words.copy(); words[hits[0]] = 0x80000000 | (1 << 20)
+                buf = (ctypes.c_ubyte * nbytes).from_buffer_copy(words.tobytes())
+                return original(name, dims, buf, nbytes)
+            return original(name, dims, args, nbytes)
+        from harness import HOOK
+        cb = HOOK(damaged)
+        L.emu_set_launch_hook(cb)
+        g.render(1, SEEDS[1:2])
+        with pytest.raises(gi.StrayAccess, match="outside every allocation"):
+            run.check()
+    g.close()
