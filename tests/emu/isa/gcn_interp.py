@@ -230,6 +230,7 @@ class Machine:
         # marks its destination registers as in flight (vector memory: vmcnt, LDS and scalar memory: lgkmcnt, results of one
         # counter arriving in the order issued); an instruction that names a register still in flight is recorded in
         # `wait_violations`: the interpreter itself would have read the right value, the machine a stale one.
+        self.histogram = None         # set to [0] * len(kernel.instrs) to count how often each instruction runs (instruction_mix)
         self.check_waits = check_waits
         self.wait_violations = []
         self.access = [self._registers_named(ins) for ins in kernel.instrs] if check_waits else None
@@ -298,6 +299,18 @@ class Machine:
             for m in re.finditer(r"\b([vs])\[(\d+):(\d+)\]", a):
                 out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
         return out
+
+    def instruction_mix(self):
+        """Executed wave-instructions by kind (needs `histogram`): vector ALU, scalar ALU, branches, vector memory (global and
+        scratch), LDS, scalar memory, waits and other."""
+        mix = {}
+        for ins, n in zip(self.k.instrs, self.histogram):
+            op = ins.op
+            kind = ("vmem" if op.startswith(("global_", "flat_")) else "scratch" if op.startswith("scratch_") else "lds" if op.startswith("ds_") else
+                    "smem" if op.startswith("s_load") else "wait" if op in ("s_waitcnt", "s_nop") else
+                    "branch" if op.startswith(("s_cbranch", "s_branch")) else "valu" if op.startswith("v_") else "salu")
+            mix[kind] = mix.get(kind, 0) + n
+        return mix
 
     def close(self):
         for buf in self._keep:
@@ -1477,6 +1490,8 @@ class Machine:
                 trace(self, w, pc)
             if self.check_waits:
                 self._check_wait(w, pc)
+            if self.histogram is not None:
+                self.histogram[pc] += 1
             nxt = code[pc](w)
             pc = pc + 1 if nxt is None else nxt
             count += 1
