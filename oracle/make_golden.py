@@ -136,6 +136,9 @@ def ray_count_fixtures(gl, tmp, noise, sky, zoom):
                       [(4, 8, 3)])
     ray_count_fixture(gl, "dragon_small", scene_from(scenes.dragon_like(target_tris=4000), tmp + "/rc"), 48, 32, zoom, noise, sky,
                       [(3, 16, 2), (6, 4, 1)])
+    # silhouettes against the sky in the normal view: a ray that misses shows the hit record of the pixel's previous ray
+    ray_count_fixture(gl, "teapot_small", scene_from(scenes.teapot_like(target_tris=4000), tmp + "/rd"), 70, 38, DEFAULT_CAMERA, noise, sky,
+                      [(4, 1, 2), (2, 8, 2)])
 
 
 def texture_fixture(gl):

@@ -893,7 +893,10 @@ __global__ __launch_bounds__(64 * RT_WG_WAVES, RT_MIN_WAVES) void trace_kernel(S
                 L.ray = MakeRay(camPos, normalize3(pt - camPos));
                 L.throughput = mk(1.0f, 1.0f, 1.0f);
                 L.bounce = 0; L.segments = 0;
-                hitNormal = mk(0.0f, 0.0f, 0.0f);          // a new invocation starts with a blank hit record
+                // A new invocation starts with a blank hit record. (The shader never initialises it, F:381, and its normal
+                // view shows the record's normal even after a miss, F:389: zeros on the parity target for a pixel's first ray,
+                // and for its later rays what the previous ray left there.)
+                if (!MULTI || P.sample == 0u) hitNormal = mk(0.0f, 0.0f, 0.0f);
                 begin_traversal<COUNT, ITERS>(sp, L, tl);
             }
             if (COUNT) rc.stop(3);

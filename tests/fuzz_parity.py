@@ -20,11 +20,13 @@ GENS = [("lightbox", {}), ("sponza_like", {"target_tris": 6000}), ("sponza_like"
         ("dragon_like", {"target_tris": 8000}), ("teapot_like", {"target_tris": 9000})]
 
 
-def run(cases, seed, large=False, log=print, host_buffers=False):
+def run(cases, seed, large=False, log=print, host_buffers=False, ray_counts=False):
     """Runs `cases` random configurations; returns how many of them differ from the oracle. host_buffers: shards are
     exported into host arrays instead of torch device tensors (for the host emulation of the library, whose device memory
-    is host memory)."""
+    is host memory). ray_counts: every case also draws the number of rays per pixel and frame (the shader's RAY_COUNT)
+    from 2..9, from a random stream of its own, so that the cases are otherwise the ones the same seed gives without it."""
     rng = np.random.default_rng(seed)
+    rng_rays = np.random.default_rng(seed + 7919)
     noises = [scenes.noise_texture(64, 48), scenes.noise_texture(37, 23, seed=5), scenes.noise_texture()]
     skies = [scenes.sky_cubemap(32), scenes.sky_cubemap(17, seed=9)]
     bad = 0
@@ -42,15 +44,18 @@ def run(cases, seed, large=False, log=print, host_buffers=False):
         world = int(rng.choice([1, 1, 2, 3, 5]))
         noise, sky = noises[rng.integers(len(noises))], skies[rng.integers(len(skies))]
         seeds = scenes.frame_seeds(frames + 3)[int(rng.integers(0, 3)):][:frames]
+        rays = int(rng_rays.integers(2, 10)) if ray_counts else 1
         sc = make_scene(name, **kw)
         o = Oracle(W, H, threads=16)
         setup(o, sc, noise, sky, camera=camera, bounce_limit=bl)
+        o.set_ray_count(rays)
         o.render(0, seeds)
         want = o.read_accum()
 
         def traced(rank):
             g = ra.Renderer(W, H)
             setup(g, sc, noise, sky, camera=camera, bounce_limit=bl)
+            g.set_ray_count(rays)
             if world > 1:
                 g.set_shard(rank, world)
             g.render(0, seeds[:split])
@@ -79,8 +84,9 @@ def run(cases, seed, large=False, log=print, host_buffers=False):
                 g.close()
             got = sharding.assemble_numpy(flat, W, H, world)
         n = differing_pixels(got, want)
-        log("case %2d: %-11s %6s tris  %3dx%-3d bl %2d frames %d (first launch %d) shards %d  %s" % (
-            case, name, kw.get("target_tris", "-"), W, H, bl, frames, split, world, "ok" if n == 0 else "DIFFERS in %d pixels" % n))
+        log("case %2d: %-11s %6s tris  %3dx%-3d bl %2d frames %d (first launch %d) shards %d%s  %s" % (
+            case, name, kw.get("target_tris", "-"), W, H, bl, frames, split, world, " rays %d" % rays if ray_counts else "",
+            "ok" if n == 0 else "DIFFERS in %d pixels" % n))
         bad += n != 0
     log("%d cases, %d with differences, %.0f s" % (cases, bad, time.time() - t0))
     return bad
@@ -88,4 +94,4 @@ def run(cases, seed, large=False, log=print, host_buffers=False):
 
 if __name__ == "__main__":
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
-                      large=len(sys.argv) > 3 and sys.argv[3] == "large") else 0)
+                      large="large" in sys.argv[3:], ray_counts="rays" in sys.argv[3:]) else 0)

@@ -47,13 +47,12 @@ def test_reproduces_reference_fixture(path):
     g.close()
 
 
-def test_counters_shards_and_return_to_one_ray():
-    W, H = 56, 27
+def test_counters_shards_and_return_to_one_ray(W=56, H=27, ray_counts=(2, 7)):
     sc = make_scene("sponza_like", target_tris=6000)
     g, o = ra.Renderer(W, H), Oracle(W, H)
     setup(g, sc, NOISE, SKY, bounce_limit=8)
     setup(o, sc, NOISE, SKY, bounce_limit=8)
-    for rays in (2, 7):
+    for rays in ray_counts:
         for r in (g, o):
             r.set_ray_count(rays)
             r.clear()
@@ -111,18 +110,27 @@ def test_counters_shards_and_return_to_one_ray():
     g.close()
 
 
-def test_many_frames_of_many_rays_in_one_launch():
-    """The table of per-ray jitters behind the frame records grows with frames x rays: 70 frames of 64 rays need more
-    than the records a context starts with."""
+def test_many_frames_of_many_rays_in_one_launch(frames=70):
+    """The table of per-ray jitters behind the frame records grows with frames x rays: 70 frames of 64 rays (and already 6)
+    need more than the 64 records a context starts with."""
     W, H = 8, 8
     sc = make_scene("lightbox")
     g, o = ra.Renderer(W, H), Oracle(W, H)
     setup(g, sc, NOISE, SKY, bounce_limit=4)
     setup(o, sc, NOISE, SKY, bounce_limit=4)
-    seeds = scenes.frame_seeds(70)
+    seeds = scenes.frame_seeds(frames)
     for r in (g, o):
         r.set_ray_count(64)
         r.clear()
         r.render(0, seeds)
     assert differing_pixels(g.read_accum(), o.read_accum()) == 0
     g.close()
+
+
+def test_random_configurations_with_several_rays_bit_exact(cases=16):
+    """The randomised parity check (random scene, image size, camera, bounce limit, launch split, 1-5 shards), every case
+    with a random number of rays per pixel from 2 to 9."""
+    import fuzz_parity
+    lines = []
+    bad = fuzz_parity.run(cases, 4242, log=lines.append, host_buffers=_emulated(), ray_counts=True)
+    assert bad == 0, "\n".join(l for l in lines if "DIFFERS" in l)
