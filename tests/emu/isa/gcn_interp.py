@@ -58,9 +58,6 @@ class Kernel:
         self.meta = None
 
 
-_MOD_FLAGS = {"clamp", "sc0", "sc1", "nt", "glc", "slc", "gds", "off"}
-
-
 def _split_operands(s):
     out, depth, cur = [], 0, ""
     for ch in s:
@@ -77,10 +74,27 @@ def _split_operands(s):
     return out
 
 
+def _split_blanks(s):
+    """Splits at blanks that are outside parentheses: 'hwreg(HW_REG_MODE, 4, 2)' stays whole."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        depth += ch == "("
+        depth -= ch == ")"
+        if ch.isspace() and depth == 0:
+            if cur:
+                out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur:
+        out.append(cur)
+    return out or [""]
+
+
 def parse_assembly(path):
     """Returns ({kernel name: Kernel}, {data symbol: bytes}) for one device assembly file."""
     kernels, data = {}, {}
-    cur, cur_data, desc_for = None, None, None
+    cur, cur_data, desc_for = None, None, None      # function being read, data symbol being read, kernel whose descriptor is being read
     meta_lines, in_meta = [], False
     for ln, raw in enumerate(open(path), 1):
         line = raw.rstrip("\n")
@@ -100,18 +114,14 @@ def parse_assembly(path):
         m = re.match(r"^([A-Za-z_.$][\w.$]*):", code)
         if m and not code.startswith("\t"):
             name = m.group(1)
-            if name.startswith(".LBB") or name.startswith(".L"):
-                if cur is not None and not name.startswith(".Lfunc_end"):
-                    cur.labels[name] = len(cur.instrs)
-                if name.startswith(".Lfunc_end"):
-                    cur = None
-                continue
-            cur, cur_data = None, None
-            if name in kernels or True:
-                # a function label or a data label: decided by what follows
-                pending = name
-                kernels.setdefault(name, Kernel(name))
-                cur = kernels[name]
+            if name.startswith(".Lfunc_end"):
+                cur = None
+            elif name.startswith(".L"):
+                if cur is not None:
+                    cur.labels[name] = len(cur.instrs)      # a branch target inside the current function
+            else:
+                # a function or a data symbol: what follows decides (instructions, or .long words)
+                cur = kernels.setdefault(name, Kernel(name))
                 cur_data = name
                 data[name] = bytearray()
             continue
@@ -135,26 +145,18 @@ def parse_assembly(path):
         parts = st.split(None, 1)
         op = parts[0]
         rest = parts[1] if len(parts) > 1 else ""
-        # trailing modifiers are separated by blanks; operands by commas
+        # operands are separated by commas; modifiers follow the last operand, separated by blanks ("v10 dst_sel:DWORD",
+        # "off offset:24", "s[6:7] offset:16 sc0"); an instruction may also have modifiers only ("vmcnt(0) lgkmcnt(0)")
         toks = _split_operands(rest)
-        args, mods = [], {}
+        mods = {}
         if toks:
-            last = toks[-1].split()
-            # the last comma-separated piece may carry blank-separated modifiers after the operand
-            head, tail = [], []
-            for i, t in enumerate(last):
-                if i == 0 and not (":" in t and not t.startswith("v[") and not t.startswith("s[")) and t not in ("clamp", "sc0", "sc1", "nt", "glc", "slc"):
-                    head.append(t)
-                else:
-                    tail.append(t)
-            toks = toks[:-1] + ([" ".join(head)] if head else [])
-            for t in tail:
-                if ":" in t:
-                    k, v = t.split(":", 1)
-                    mods[k] = v
-                else:
-                    mods[t] = True
-        # (hwreg(...) operands contain blanks and commas inside parentheses: kept whole by _split_operands)
+            words = _split_blanks(toks[-1])
+            flags = ("clamp", "sc0", "sc1", "nt", "glc", "slc")
+            is_operand = not (words[0] in flags or (":" in words[0] and not words[0].startswith(("v[", "s["))))
+            toks = toks[:-1] + ([words[0]] if is_operand else [])
+            for t in words[1 if is_operand else 0:]:
+                k, _, v = t.partition(":")
+                mods[k] = v if v else True
         args = [a for a in toks if a != ""]
         cur.instrs.append(Instr(op, args, mods, st, ln))
     meta = yaml.safe_load("\n".join(meta_lines)) if meta_lines else {"amdhsa.kernels": []}
