@@ -141,3 +141,21 @@ def test_a_stray_address_is_reported_not_followed(assembly):
         with pytest.raises(gi.StrayAccess, match="outside every allocation"):
             run.check()
     g.close()
+
+
+def test_the_benchmarked_kernel_keeps_its_register_and_lds_budget(assembly):
+    """What the design rests on for the one-frame kernel (five waves per SIMD, five work-groups per CU): at most 96 vector
+    registers, no scratch, exactly 25 LDS granules of 1 280 bytes. An edit that spills or grows the LDS copy shows here, on the
+    CPU, before it shows as a slower frame. The other instantiations stay within 96 registers too (they may spill)."""
+    import gcn_interp as gi
+    kernels, _ = gi.parse_assembly(assembly)
+    tracer = {k: v for k, v in kernels.items() if "12trace_kernelI" in k}
+    assert len(tracer) == 11
+    for name, k in tracer.items():
+        assert k.desc["next_free_vgpr"] <= 96, name
+        assert k.desc["group_segment_fixed_size"] <= 32000, name
+    bench = [k for n, k in tracer.items() if "trace_kernelILb0ELb0ELb1ELb0ELb0EE" in n]
+    assert len(bench) == 1
+    assert bench[0].desc["private_segment_fixed_size"] == 0
+    assert bench[0].desc["group_segment_fixed_size"] == 32000
+    assert bench[0].meta[".vgpr_spill_count"] == 0
