@@ -343,9 +343,10 @@ def test_headless_executable_on_three_imitated_devices_writes_the_same_image(tmp
     common = [exe, "--ini", str(root / "RayTracer.ini"), "--noise", str(root / "noise.png"), "--width", str(W), "--height", str(H),
               "--cache", str(tmp_path / "cache")]
     env = dict(os.environ, RT_EMU_DEVICES="3")
+    images = {}
     # (with bloom the plain loop runs the chain per displayed frame and carries its tmp texture over, the group once on the
     # gathered image: same image for one frame only; without bloom for any number of frames)
-    for tag, extra in (("bloom1", ["--frames", "1"]), ("plain5", ["--frames", "5", "--no-bloom"])):
+    for tag, extra in (("bloom1", ["--frames", "1"]), ("plain5", ["--frames", "5", "--no-bloom"]), ("rays3", ["--frames", "2", "--no-bloom", "--ray-count", "3"])):
         one = subprocess.run(common + extra + ["--out", str(tmp_path / ("one" + tag))], capture_output=True, text=True, timeout=300, env=env)
         assert one.returncode == 0, one.stdout + one.stderr
         grp = subprocess.run(common + extra + ["--gpus", "3", "--out", str(tmp_path / ("grp" + tag))], capture_output=True, text=True, timeout=300, env=env)
@@ -354,6 +355,8 @@ def test_headless_executable_on_three_imitated_devices_writes_the_same_image(tmp
         a, b = np.asarray(Image.open(str(tmp_path / ("one" + tag + ".png")))), np.asarray(Image.open(str(tmp_path / ("grp" + tag + ".png"))))
         assert a.shape == (H, W, 3) and a.max() > 40
         assert (a == b).all(), tag
+        images[tag] = a
+    assert (images["rays3"] != images["plain5"]).any()          # (the option reached the kernels)
     extra = ["--frames", "1"]
     four = subprocess.run(common + extra + ["--gpus", "4", "--out", str(tmp_path / "four")], capture_output=True, text=True, timeout=300, env=env)
     assert four.returncode != 0 and "device" in (four.stdout + four.stderr).lower()      # more ranks than devices: refused, not crashed
