@@ -566,7 +566,9 @@ static FrameParams MakeFrame(const rt_context* c, uint32_t index, const float* s
 // jitters (8 bytes each) follow the n frame records; prepare_rays_kernel fills both in.
 static int UploadFrames(rt_context* c, uint32_t first, uint32_t n, const float* seeds3, uint32_t rays) {
     const uint64_t records = rays > 1u ? (uint64_t)n + 1u + ((uint64_t)n * rays * 8u + sizeof(FrameParams) - 1u) / sizeof(FrameParams) : n;
-    if (records > 0x7fffffffull / sizeof(FrameParams)) return Fail(c, RT_ERR_UNSUPPORTED, "rt_render: %u frames of %u rays are too many for one launch", n, rays);
+    // (the kernels index the jitter table with a 24-bit multiply of the frame number)
+    if (records > 0x7fffffffull / sizeof(FrameParams) || (rays > 1u && n >= (1u << 24)))
+        return Fail(c, RT_ERR_UNSUPPORTED, "rt_render: %u frames of %u rays are too many for one launch", n, rays);
     if (records > c->framesCap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->dFrames) (void)hipFree(c->dFrames);

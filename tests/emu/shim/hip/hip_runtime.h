@@ -147,6 +147,7 @@ template <class T> static inline void PackOne(unsigned char* buf, size_t& at, co
 bool OfferLaunch(const char* kernel, dim3 grid, dim3 block, const unsigned char* args, size_t bytes);
 template <class... A> static inline bool Offer(const char* kernel, dim3 grid, dim3 block, const A&... a) {
     alignas(16) unsigned char buf[1024];
+    static_assert((sizeof(A) + ... + 0) + 16 * sizeof...(A) <= sizeof buf, "kernel arguments larger than the packing buffer");
     memset(buf, 0, sizeof buf);
     size_t at = 0;
     (PackOne(buf, at, a), ...);
