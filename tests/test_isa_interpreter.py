@@ -159,3 +159,21 @@ def test_the_benchmarked_kernel_keeps_its_register_and_lds_budget(assembly):
     assert bench[0].desc["private_segment_fixed_size"] == 0
     assert bench[0].desc["group_segment_fixed_size"] == 32000
     assert bench[0].meta[".vgpr_spill_count"] == 0
+
+
+def test_one_ray_kernels_are_the_instruction_streams_that_ran_on_the_gpu(assembly):
+    """profiles/r03_kernel_isa_hashes.json holds fingerprints of the seven one-ray kernels as they were built for the profile
+    r03a and the GPU test run before it (the sources of that commit give the same fingerprints). The current sources must
+    still compile to exactly those instructions: what was added since (the kernels for several rays per pixel) lives in
+    instantiations of its own. Skipped under another compiler version, where the streams differ for other reasons."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_isa_hashes as kh
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_kernel_isa_hashes.json")) as f:
+        recorded = json.load(f)
+    if recorded["toolchain"] != kh.toolchain():
+        pytest.skip("recorded with another compiler: " + recorded["toolchain"])
+    now = kh.fingerprints(assembly)
+    assert len(recorded["kernels"]) == 7
+    for name, fp in recorded["kernels"].items():
+        assert now[name] == fp, name
