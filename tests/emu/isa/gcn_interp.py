@@ -7,10 +7,11 @@ checked against the runtime's table of allocations. It exists to look below sour
 source is right (the fiber emulation agrees with the oracle) and whose machine code is not shows here, and a stray
 address is reported with its instruction instead of faulting a machine.
 
-Scope: the instructions these kernels use (about 180 opcodes of SOP*, VOP*, DS, GLOBAL, SCRATCH, SMEM), single precision
-with the mode register's denormal control honoured, no timing, no hardware hazards (a missing s_nop or s_waitcnt cannot
-show). v_rcp_f32 and v_rsq_f32 return correctly rounded results where the hardware is within one ulp: the kernels'
-division and square-root sequences correct their estimate to the exact result either way.
+Scope: the instructions these kernels use (about 200 opcodes of SOP*, VOP* with SDWA, DS, GLOBAL, SCRATCH, SMEM), single
+precision with the mode register's denormal control honoured, launches of up to three dimensions, no timing, no hardware
+hazards (a missing s_nop cannot show; a missing s_waitcnt can, see check_waits). v_rcp_f32, v_rsq_f32, v_exp_f32 and
+v_log_f32 return correctly rounded results where the hardware is within one ulp: the tracer's division and square-root
+sequences correct their estimate to the exact result either way, the bloom chain is compared within a tolerance.
 """
 import ctypes
 import re
@@ -237,6 +238,7 @@ class Machine:
         self.wait_violations = []
         self.access = [self._registers_named(ins) for ins in kernel.instrs] if check_waits else None
         self.executed = 0
+        self.lds_debug = None         # a list: collects (instruction index, addresses) of LDS accesses out of range
         self.lds_out_of_range = 0     # lane accesses beyond the work-group's LDS (the hardware returns 0 / drops the write)
         self.compiled = [self._compile(i, ins) for i, ins in enumerate(kernel.instrs)]
 
@@ -473,7 +475,12 @@ class Machine:
                 raise Unsupported("%s (assembly line %d)" % (ins.text, ins.line))
             return bad
         try:
-            return fn(a, mods, sdwa, ins) if four else fn(a, mods)
+            run = fn(a, mods, sdwa, ins) if four else fn(a, mods)
+            if sdwa and mods.get("dst_sel", "DWORD") != "DWORD":
+                run = self._sdwa_destination(run, a, mods)
+            if sdwa and not four and any(mods.get("src%d_sel" % i, "DWORD") != "DWORD" for i in range(2)):
+                raise Unsupported("sdwa source selector on this instruction")
+            return run
         except Unsupported as e:
             msg = "%s: %s (assembly line %d)" % (ins.text, e, ins.line)
 
@@ -491,10 +498,13 @@ class Machine:
         }
         if base in f2:
             return lambda a, mods, sdwa, ins, f=f2[base]: self._valu_f(a, mods, f, 2)
-        f3 = {"v_min3_f32": lambda x, y, z: np.fmin(np.fmin(x, y), z), "v_max3_f32": lambda x, y, z: np.fmax(np.fmax(x, y), z)}
+        f3 = {"v_min3_f32": lambda x, y, z: np.fmin(np.fmin(x, y), z), "v_max3_f32": lambda x, y, z: np.fmax(np.fmax(x, y), z),
+              # (the median of three; with a NaN among them the hardware returns min3, which the fmin chain gives as well)
+              "v_med3_f32": lambda x, y, z: np.where(np.isnan(x) | np.isnan(y) | np.isnan(z), np.fmin(np.fmin(x, y), z),
+                                                     np.fmax(np.fmin(x, y), np.fmin(np.fmax(x, y), z)))}
         if base in f3:
             return lambda a, mods, sdwa, ins, f=f3[base]: self._valu_f(a, mods, f, 3)
-        f1 = {"v_floor_f32": np.floor, "v_rndne_f32": np.rint}
+        f1 = {"v_floor_f32": np.floor, "v_rndne_f32": np.rint, "v_trunc_f32": np.trunc}
         if base in f1:
             return lambda a, mods, sdwa, ins, f=f1[base]: self._valu_f(a, mods, f, 1)
         u2 = {
@@ -506,6 +516,8 @@ class Machine:
             "v_mul_hi_u32": lambda x, y: ((x.astype(U64) * y.astype(U64)) >> U64(32)).astype(U32),
             "v_mul_u32_u24": lambda x, y: ((x & U32(0xffffff)).astype(U64) * (y & U32(0xffffff)).astype(U64)).astype(U32),
             "v_min_u32": np.minimum, "v_max_u32": np.maximum,
+            "v_mul_lo_u16": lambda x, y: (x * y) & U32(0xffff), "v_sub_u16": lambda x, y: (x - y) & U32(0xffff),
+            "v_add_u16": lambda x, y: (x + y) & U32(0xffff),
             "v_min_i32": lambda x, y: np.minimum(x.view(I32), y.view(I32)).view(U32),
             "v_max_i32": lambda x, y: np.maximum(x.view(I32), y.view(I32)).view(U32),
         }
@@ -513,6 +525,9 @@ class Machine:
             return lambda a, mods, sdwa, ins, f=u2[base]: self._valu_u(a, mods, f, 2, sdwa)
         u3 = {
             "v_add3_u32": lambda x, y, z: x + y + z,
+            "v_min3_i32": lambda x, y, z: np.minimum(np.minimum(x.view(I32), y.view(I32)), z.view(I32)).view(U32),
+            "v_max3_i32": lambda x, y, z: np.maximum(np.maximum(x.view(I32), y.view(I32)), z.view(I32)).view(U32),
+            "v_bfi_b32": lambda x, y, z: (x & y) | (~x & z),
             "v_lshl_add_u32": lambda x, y, z: (x << (y & U32(31))) + z,
             "v_add_lshl_u32": lambda x, y, z: (x + y) << (z & U32(31)),
             "v_lshl_or_b32": lambda x, y, z: (x << (y & U32(31))) | z,
@@ -580,6 +595,26 @@ class Machine:
             self.vwrite(w, d, r.view(U32))
         return run
 
+    def _sdwa_destination(self, run, a, mods):
+        """The instruction's result goes to one byte or half of the destination; the rest is zeroed or kept."""
+        d = self._reg(a[0])[1]
+        sel, unused = mods["dst_sel"], mods.get("dst_unused", "UNUSED_PAD")
+        m = re.fullmatch(r"(BYTE|WORD)_(\d)", sel)
+        if not m or unused not in ("UNUSED_PAD", "UNUSED_PRESERVE"):
+            raise Unsupported("sdwa destination %s %s" % (sel, unused))
+        bits_ = 8 if m.group(1) == "BYTE" else 16
+        shift = U32(bits_ * int(m.group(2)))
+        field = U32(((1 << bits_) - 1))
+
+        def wrapped(w):
+            old = w.V[d].copy()
+            run(w)
+            placed = (w.V[d] & field) << shift
+            if unused == "UNUSED_PRESERVE":
+                placed |= old & ~(field << shift)
+            w.V[d][:] = np.where(w.em, placed, old)
+        return wrapped
+
     def _sdwa_sel(self, x, sel):
         if sel in (None, "DWORD"): return x
         m = re.fullmatch(r"BYTE_(\d)", sel)
@@ -592,8 +627,6 @@ class Machine:
         d = self._reg(a[0])[1]
         srcs = [self.srcu(t) for t in a[1:1 + n]]
         sels = [mods.get("src%d_sel" % i) for i in range(n)] if sdwa else None
-        if sdwa and mods.get("dst_sel", "DWORD") != "DWORD":
-            raise Unsupported("sdwa destination selector")
 
         def run(w):
             xs = [g(w) for g in srcs]
@@ -829,6 +862,20 @@ class Machine:
             r = (sx >> (gb(w) & 31)) & 0xffffffff; put(w, r); w.scc = 1 if r else 0
         return run
 
+    def _sminmax_i32(self, a, pick_max):
+        put, ga, gb = self.dst32s(a[0]), self.src32(a[1]), self.src32(a[2])
+
+        def run(w):
+            x, y = ga(w), gb(w)
+            sx = x - (1 << 32) if x & 0x80000000 else x
+            sy = y - (1 << 32) if y & 0x80000000 else y
+            first = sx > sy if pick_max else sx < sy
+            put(w, x if first else y); w.scc = 1 if first else 0
+        return run
+
+    def op_s_max_i32(self, a, mods): return self._sminmax_i32(a, True)
+    def op_s_min_i32(self, a, mods): return self._sminmax_i32(a, False)
+
     def op_s_min_u32(self, a, mods):
         put, ga, gb = self.dst32s(a[0]), self.src32(a[1]), self.src32(a[2])
 
@@ -960,6 +1007,114 @@ class Machine:
             with np.errstate(all="ignore"):
                 r = (F32(1) / x).astype(F32)
             self.vwrite(w, d, _flush(r).view(U32))
+        return run
+
+    def op_v_fmamk_f32(self, a, mods):          # D = S0 * K + S1
+        d = self._reg(a[0])[1]
+        g0, gk, g1 = self.srcf(a[1]), self.srcf(a[2]), self.srcf(a[3])
+        return lambda w: self.vwrite(w, d, self._fma(w, g0(w), gk(w), g1(w)).view(U32))
+
+    def op_v_fmaak_f32(self, a, mods):          # D = S0 * S1 + K
+        d = self._reg(a[0])[1]
+        g0, g1, gk = self.srcf(a[1]), self.srcf(a[2]), self.srcf(a[3])
+        return lambda w: self.vwrite(w, d, self._fma(w, g0(w), g1(w), gk(w)).view(U32))
+
+    def op_v_exp_f32(self, a, mods):            # 2^x; the hardware's result is within one ulp of this one
+        d, g = self._reg(a[0])[1], self.srcf(a[1])
+
+        def run(w):
+            with np.errstate(all="ignore"):
+                r = np.exp2(_flush(g(w)).astype(np.float64)).astype(F32)
+            self.vwrite(w, d, _flush(r).view(U32))
+        return run
+
+    def op_v_log_f32(self, a, mods):            # log2 x; likewise
+        d, g = self._reg(a[0])[1], self.srcf(a[1])
+
+        def run(w):
+            with np.errstate(all="ignore"):
+                r = np.log2(_flush(g(w)).astype(np.float64)).astype(F32)
+            self.vwrite(w, d, _flush(r).view(U32))
+        return run
+
+    def op_v_ldexp_f32(self, a, mods):
+        d, g0, g1 = self._reg(a[0])[1], self.srcf(a[1]), self.srcu(a[2])
+
+        def run(w):
+            x = g0(w)
+            if w.flush: x = _flush(x)
+            with np.errstate(all="ignore"):
+                r = np.ldexp(x.astype(np.float64), np.clip(g1(w).view(I32), -400, 400)).astype(F32)
+            self.vwrite(w, d, (_flush(r) if w.flush else r).view(U32))
+        return run
+
+    def op_v_frexp_mant_f32(self, a, mods):
+        d, g = self._reg(a[0])[1], self.srcf(a[1])
+
+        def run(w):
+            x = g(w)
+            if w.flush: x = _flush(x)
+            with np.errstate(all="ignore"):
+                m, _ = np.frexp(x)
+            self.vwrite(w, d, np.where(np.isfinite(x), m, x).astype(F32).view(U32))      # infinities and NaNs pass through
+        return run
+
+    def op_v_frexp_exp_i32_f32(self, a, mods):
+        d, g = self._reg(a[0])[1], self.srcf(a[1])
+
+        def run(w):
+            x = g(w)
+            if w.flush: x = _flush(x)
+            with np.errstate(all="ignore"):
+                _, e = np.frexp(x)
+            self.vwrite(w, d, np.where(np.isfinite(x) & (x != 0), e, 0).astype(I32).view(U32))
+        return run
+
+    def op_v_cvt_f64_f32(self, a, mods):
+        d, g = self._reg(a[0])[1], self.srcf(a[1])
+
+        def run(w):
+            x = g(w)
+            if w.flush: x = _flush(x)
+            with np.errstate(all="ignore"):
+                self.vwrite64(w, d, x.astype(np.float64).view(U64))
+        return run
+
+    def op_v_frexp_exp_i32_f64(self, a, mods):
+        d, g = self._reg(a[0])[1], self.src64v(a[1])
+
+        def run(w):
+            x = g(w).view(np.float64)
+            with np.errstate(all="ignore"):
+                _, e = np.frexp(x)
+            self.vwrite(w, d, np.where(np.isfinite(x) & (x != 0), e, 0).astype(I32).view(U32))
+        return run
+
+    def op_v_mad_i64_i32(self, a, mods):
+        d = self._reg(a[0])[1]
+        put = self.lanemask_dst(a[1])
+        g0, g1, g2 = self.srcu(a[2]), self.srcu(a[3]), self.src64v(a[4])
+
+        def run(w):
+            p = g0(w).view(I32).astype(np.int64) * g1(w).view(I32).astype(np.int64)
+            with np.errstate(over="ignore"):
+                r = p + g2(w).view(np.int64)
+            put(w, 0)          # (the carry-out is not used by these kernels; a use would name the register, which reads as zero)
+            self.vwrite64(w, d, r.view(U64))
+        return run
+
+    def op_v_bitop3_b16(self, a, mods):
+        d = self._reg(a[0])[1]
+        gs = [self.srcu(t) for t in a[1:4]]
+        table = int(mods["bitop3"], 0)
+
+        def run(w):
+            x, y, z = (g(w) for g in gs)
+            r = np.zeros(64, U32)
+            for i in range(8):
+                if table >> i & 1:
+                    r |= (x if i & 4 else ~x) & (y if i & 2 else ~y) & (z if i & 1 else ~z)
+            self.vwrite(w, d, (w.V[d] & U32(0xffff0000)) | (r & U32(0xffff)))      # the low half is written, the high half kept
         return run
 
     def op_v_rcp_iflag_f32(self, a, mods): return self.op_v_rcp_f32(a, mods)
@@ -1229,9 +1384,11 @@ class Machine:
 
     # ---- LDS ----
     def _lds_index(self, w, addr, extra, ndw):
-        a = addr.astype(np.int64) + extra
+        a = (addr.astype(np.int64) + extra) & 0xffffffff      # (32-bit address arithmetic: the compiler uses a "negative" base with an offset)
         ok = w.em & (a >= 0) & (a + 4 * ndw <= self.lds_bytes)
         self.lds_out_of_range += int((w.em & ~ok).sum())
+        if self.lds_debug is not None and (w.em & ~ok).any():
+            self.lds_debug.append((w.pc, a[w.em & ~ok][:4].tolist()))
         if (a[w.em] & 3).any():
             raise Unsupported("unaligned LDS access")
         return a >> 2, ok
@@ -1356,6 +1513,25 @@ class Machine:
     def op_flat_load_dwordx2(self, a, mods, sdwa, ins): return self._gload(a + ["off"], mods, 2, ins)
     def op_flat_load_dwordx4(self, a, mods, sdwa, ins): return self._gload(a + ["off"], mods, 4, ins)
 
+    def _gstore_small(self, a, mods, nbytes, ins):
+        s = self._reg(a[1])[1]
+        ga = self._addr(a[0], a[2], mods)
+        lib = self.lib
+
+        def run(w):
+            if not w.exec: return
+            addr = ga(w)
+            for l in range(64):
+                if not w.em[l]: continue
+                p = int(addr[l])
+                if not lib.emu_known(p, nbytes):
+                    self._stray(w, "store", ins, addr, 1 << l)
+                ctypes.memmove(p, int(w.V[s][l]).to_bytes(4, "little")[:nbytes], nbytes)
+        return run
+
+    def op_global_store_byte(self, a, mods, sdwa, ins): return self._gstore_small(a, mods, 1, ins)
+    def op_global_store_short(self, a, mods, sdwa, ins): return self._gstore_small(a, mods, 2, ins)
+
     def op_global_store_dword(self, a, mods, sdwa, ins): return self._gstore(a, mods, 1, ins)
     def op_global_store_dwordx2(self, a, mods, sdwa, ins): return self._gstore(a, mods, 2, ins)
     def op_global_store_dwordx3(self, a, mods, sdwa, ins): return self._gstore(a, mods, 3, ins)
@@ -1410,7 +1586,7 @@ class Machine:
     # ---- running ----
     def _kernarg(self, args, grid, block):
         size = int(self.k.desc.get("kernarg_size", len(args)))
-        buf = bytearray(max(size, len(args)))
+        buf = bytearray(max(size, len(args)) + 64)      # (the compiler may read a whole dwordx8 where fewer words are arguments)
         buf[:len(args)] = args
         for arg in self.k.meta[".args"]:
             kind, off = arg[".value_kind"], arg[".offset"]
@@ -1427,19 +1603,19 @@ class Machine:
         """grid, block: 3-tuples; args: the explicit kernel arguments as the device lays them out. The waves of a work-group
         take turns of `time_slice` instructions (they share LDS and race for the tile queues, as on the machine);
         work-groups run one after the other."""
-        if block[1] != 1 or block[2] != 1 or grid[1] != 1 or grid[2] != 1:
-            raise Unsupported("launches of more than one dimension")
+        threads = block[0] * block[1] * block[2]
         karg = self._kernarg(bytes(args), grid, block)
         kbuf = ctypes.create_string_buffer(bytes(karg), len(karg))
         self.lib.emu_register_range(ctypes.addressof(kbuf), len(karg))
         d = self.k.desc
         try:
-            for g in range(grid[0]):
+            for g in range(grid[0] * grid[1] * grid[2]):
+                gx, gy, gz = g % grid[0], g // grid[0] % grid[1], g // (grid[0] * grid[1])
                 self.lds = np.zeros(self.lds_bytes // 4 + 16, U32)
                 if self.garbage is not None:
                     self.lds[:] = self.garbage.integers(0, 1 << 32, size=self.lds.size, dtype=np.uint64).astype(U32)
                 waves = []
-                for wi in range((block[0] + 63) // 64):
+                for wi in range((threads + 63) // 64):
                     w = Wave(self.nv)
                     if self.garbage is not None:
                         w.V[:] = self.garbage.integers(0, 1 << 32, size=w.V.shape, dtype=np.uint64).astype(U32)
@@ -1455,12 +1631,14 @@ class Machine:
                     if d.get("user_sgpr_private_segment_size"): s += 1
                     if d.get("user_sgpr_kernarg_preload_length"): raise Unsupported("kernel-argument preload")
                     if s != d.get("user_sgpr_count", s): raise Unsupported("user SGPR layout")
-                    if d.get("system_sgpr_workgroup_id_x"): w.S[s] = g; s += 1
-                    if d.get("system_sgpr_workgroup_id_y"): w.S[s] = 0; s += 1
-                    if d.get("system_sgpr_workgroup_id_z"): w.S[s] = 0; s += 1
+                    if d.get("system_sgpr_workgroup_id_x"): w.S[s] = gx; s += 1
+                    if d.get("system_sgpr_workgroup_id_y"): w.S[s] = gy; s += 1
+                    if d.get("system_sgpr_workgroup_id_z"): w.S[s] = gz; s += 1
                     tid = np.arange(64, dtype=U32) + U32(64 * wi)
-                    live = tid < block[0]
-                    w.V[0][:] = np.where(live, tid, 0)
+                    live = tid < threads
+                    # the work-item id arrives packed in v0: x in bits 0-9, y in 10-19, z in 20-29
+                    tx, ty, tz = tid % U32(block[0]), tid // U32(block[0]) % U32(block[1]), tid // U32(block[0] * block[1])
+                    w.V[0][:] = np.where(live, tx | (ty << U32(10)) | (tz << U32(20)), 0)
                     w.set_exec(bools_to_mask(live))
                     w.flush = d.get("float_denorm_mode_32", 0) == 0
                     w.scratch = np.full((64, max(self.scratch_bytes // 4, 1)), 0xdeadbeef, U32)

@@ -53,6 +53,7 @@ class FromAssembly:
         self.launches = []          # (kernel name, grid, instructions executed, LDS accesses out of range)
         self.error = None
         self.machines = {}
+        self._shared = []
 
     def _hook(self, name, dims, args, nbytes):
         try:
@@ -85,9 +86,19 @@ class FromAssembly:
 
     def __exit__(self, *exc):
         self.lib.emu_set_launch_hook(HOOK(0))
+        for a in self._shared:
+            self.lib.emu_forget_range(ctypes.c_void_p(a.ctypes.data))
         for m in self.machines.values():
             m.close()
         return False
+
+    def share(self, *arrays):
+        """Host arrays handed to the library as if they were device buffers (the emulation's device memory is host memory)
+        are no allocations of the runtime: this enters them in its table, so that the interpreter's address check accepts
+        them, until the block ends."""
+        for a in arrays:
+            self.lib.emu_register_range(ctypes.c_void_p(a.ctypes.data), ctypes.c_size_t(a.nbytes))
+            self._shared.append(a)
 
     def wait_violations(self):
         """Instructions that named a register whose memory result had not been waited for (check_waits=True)."""

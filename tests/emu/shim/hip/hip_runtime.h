@@ -27,7 +27,7 @@
 #define __shared__ static thread_local          // one copy per work-group: each work-group runs on one host thread
 #define __constant__ static const
 #define __align__(n) __attribute__((aligned(n)))
-#define HIP_SYMBOL(x) (&(x))
+#define HIP_SYMBOL(x) (::emu::Symbol{&(x), sizeof(x)})
 #define __HIP_MEMORY_SCOPE_AGENT 0
 
 struct alignas(8) uint2 { uint32_t x, y; };
@@ -76,6 +76,7 @@ static inline uint32_t atomicMax(uint32_t* p, uint32_t v) {
 
 // ---- wave- and block-wide operations: every lane that is still running must arrive at the same one ----
 namespace emu {
+struct Symbol { const void* address; size_t bytes; };
 enum Collective { kBallot = 1, kFirstLane, kShuffleDown, kBarrier };
 uint64_t WaveExchange(int kind, uint64_t value, unsigned offset);
 void BlockBarrier();
@@ -131,7 +132,13 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventQuery(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
-static inline hipError_t hipGetSymbolAddress(void** p, const void* symbol) { *p = const_cast<void*>(symbol); return hipSuccess; }
+// (a __device__ variable is a host variable here; its address enters the table of device allocations, see emu_register_range)
+extern "C" void emu_register_range(const void* p, size_t bytes);
+static inline hipError_t hipGetSymbolAddress(void** p, emu::Symbol symbol) {
+    *p = const_cast<void*>(symbol.address);
+    emu_register_range(symbol.address, symbol.bytes);
+    return hipSuccess;
+}
 template <class F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 1; return hipSuccess; }
 
 // A launch first offers itself, by name and with its arguments laid out as the device's kernel-argument segment (each

@@ -177,3 +177,44 @@ def test_one_ray_kernels_are_the_instruction_streams_that_ran_on_the_gpu(assembl
     assert len(recorded["kernels"]) == 7
     for name, fp in recorded["kernels"].items():
         assert now[name] == fp, name
+
+
+POST_KERNELS = ("down_kernel", "pre_kernel", "blur_kernel", "snap_kernel", "final_kernel", "to_rgb8_kernel")
+
+
+def test_machine_code_of_the_bloom_chain():
+    """post_kernels.hip from its assembly: three consecutive frames (the chain's tmp image carries over) against the post
+    oracle within the GPU test's tolerance (the hardware's exp2/log2 are within an ulp of the interpreter's), the 8-bit image
+    within one code; then the entry point that allocates nothing on two images, the second smaller, bit-equal to the
+    ordinary one run the same way. Two-dimensional launches, the LDS-tiled blur, byte and short stores, SDWA."""
+    from harness import CSRC, FromAssembly, assemble
+    from raytracing_amd import _lib
+    from rt_oracle import PostOracle
+    from test_post import TOL_GPU_ORACLE, noisy_hdr
+    from test_zz_no_alloc import hdr_image, reference_chain
+    from util import bits
+    asm = assemble(source=os.path.join(CSRC, "post_kernels.hip"), tag="post_kernels")
+    W, H = 123, 77
+    g, po = ra.Renderer(W, H), PostOracle(W, H)
+    with FromAssembly(asm, kernels=POST_KERNELS, garbage=17, check_waits=True) as run:
+        for frame in range(3):
+            a = noisy_hdr(W, H, 60 + frame)
+            g.write_accum(a)
+            rgba, rgb8 = g.postprocess(True); run.check()
+            o_rgba, o_rgb8 = po.run(a)
+            assert np.abs(rgba[..., :3] - o_rgba[..., :3]).max() <= TOL_GPU_ORACLE, frame
+            assert np.abs(rgb8.astype(int) - o_rgb8.astype(int)).max() <= 1
+        assert {l[0] for l in run.launches} == set(POST_KERNELS)
+        L = _lib.lib()
+        for img in (hdr_image(96, 54, 1), hdr_image(31, 19, 2)):
+            h, w = img.shape[:2]
+            rgba = np.full((h, w, 4), -1.0, dtype=np.float32)
+            rgb8 = np.full((h, w, 3), 7, dtype=np.uint8)
+            run.share(img, rgba, rgb8)
+            assert L.rt_postprocess_static(img.ctypes.data, w, h, rgba.ctypes.data, rgb8.ctypes.data, None) == 0; run.check()
+            want_rgba, want_rgb8 = reference_chain(img); run.check()
+            assert (bits(rgba) == bits(want_rgba)).all()
+            assert (rgb8 == want_rgb8).all()
+        assert run.wait_violations() == []
+        assert sum(l[3] for l in run.launches) == 0
+    g.close()
