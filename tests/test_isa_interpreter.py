@@ -24,7 +24,9 @@ pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reaso
 NOISE = scenes.noise_texture(64, 48)
 SKY = scenes.sky_cubemap(32)
 SEEDS = scenes.frame_seeds(6)
-KERNELS = ("trace_kernel", "prepare_frames_kernel", "prepare_rays_kernel")
+# every kernel of trace_kernels.hip: the tracer, the two that prepare a launch, and the helpers (image layout, tile order, tallies)
+KERNELS = ("trace_kernel", "prepare_frames_kernel", "prepare_rays_kernel", "untile_kernel", "retile_kernel", "reduce_tally_kernel",
+           "order_keys_kernel", "probe_triangles_kernel")
 
 
 @pytest.fixture(scope="module")
@@ -99,7 +101,8 @@ def test_machine_code_of_every_tracer_kernel_equals_the_oracle(assembly, scene, 
         seen.add(run.launches[-1][0])
         assert run.wait_violations() == []
     assert len([s for s in seen if "trace_kernel" in s]) == (11 if scene == "lightbox" else 5), sorted(seen)
-    assert any("prepare_rays_kernel" in s for s in seen) and any("prepare_frames_kernel" in s for s in seen)
+    for helper in ("prepare_rays_kernel", "prepare_frames_kernel", "untile_kernel", "reduce_tally_kernel", "order_keys_kernel"):
+        assert any(helper in s for s in seen), helper
     g.close()
 
 
@@ -217,4 +220,23 @@ def test_machine_code_of_the_bloom_chain():
             assert (rgb8 == want_rgb8).all()
         assert run.wait_violations() == []
         assert sum(l[3] for l in run.launches) == 0
+    g.close()
+
+
+def test_machine_code_of_the_triangle_test_on_shared_edges(assembly):
+    """probe_triangles_kernel (the leaf body's ray/triangle test on caller-supplied pairs) from its assembly, on rays aimed at
+    triangle edges, against what the reference's own hitTriangle returned on llvmpipe (tests/golden/triangle_edges.npz):
+    which side of an edge a hit falls on is decided by the last bit, so the division sequence and the order of the
+    operations in the compiled code are what is being checked."""
+    from harness import FromAssembly
+    from util import GOLDEN, bits
+    t = np.load(os.path.join(GOLDEN, "triangle_edges.npz"))
+    n = len(t["hit"])
+    g = ra.Renderer(8, 8)
+    with FromAssembly(assembly, kernels=("probe_triangles_kernel",), garbage=3, check_waits=True) as run:
+        hit, dist = g.probe_triangles(t["tri12"][:n], t["origins"][:n], t["directions"][:n]); run.check()
+        assert len(run.launches) == 1 and run.wait_violations() == []
+    assert (hit == t["hit"][:n]).all()
+    assert (bits(dist)[hit] == bits(t["t"][:n])[hit]).all()
+    assert 0.2 < hit.mean() < 0.95
     g.close()
