@@ -16,7 +16,7 @@ build() {   # name, patches (joined by +), extra compiler options
     local tmp; tmp=$(mktemp -d /tmp/rt_variant_XXXX)
     git -C "$ROOT" worktree add --detach "$tmp/tree" HEAD >/dev/null 2>&1
     ( cd "$tmp/tree" && for p in ${patches//+/ }; do git apply "$ROOT/profiles/$p"; done && cd raytracing_amd/csrc &&
-      make -s HIPCC="/opt/rocm/bin/hipcc $*" >/dev/null && cp ../librt_mi355x.so "$OUT/$name.so" )
+      make -s HIPCC="/opt/rocm/bin/hipcc $*" >/dev/null 2>&1 && cp ../librt_mi355x.so "$OUT/$name.so" )
     git -C "$ROOT" worktree remove --force "$tmp/tree"; rm -rf "$tmp"
     echo "built build_variants/$name.so"
 }
