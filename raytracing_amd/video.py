@@ -82,6 +82,7 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--ray-count", type=int, default=1, help="rays per pixel and frame: the shader's compile-time RAY_COUNT (Fragment.glsl:5)")
     ap.add_argument("--scene", default="sponza_like")
     ap.add_argument("--tris", type=int, default=260_000)
     ap.add_argument("--out", default="shots")
@@ -121,6 +122,7 @@ def main(argv=None):
     r.set_noise(scenes.noise_texture())
     r.set_skybox(scenes.sky_cubemap())
     r.set_bounce_limit(args.bounces)
+    r.set_ray_count(args.ray_count)
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
