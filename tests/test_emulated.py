@@ -407,6 +407,13 @@ def test_several_rays_per_pixel_counters_shards_and_long_launches():
     test_zy_ray_count_gpu.test_many_frames_of_many_rays_in_one_launch(frames=6)
 
 
+def test_the_drivers_smoke_entry_point(capsys):
+    """__graft_entry__.smoke(), the call the driver makes on a GPU before the benchmark, with the emulated library."""
+    import __graft_entry__
+    __graft_entry__.smoke()
+    assert "pixels differing from the oracle: 0; primary ids equal: True" in capsys.readouterr().out
+
+
 @pytest.mark.parametrize("cus,threads", [(1, 1), (3, 2), (40, 4)])
 def test_any_grid_size_gives_the_same_image(cus, threads):
     """The persistent grid is sized to the machine: one work-group that takes every tile, a few, and far more waves than
