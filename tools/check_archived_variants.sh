@@ -1,7 +1,8 @@
 #!/bin/bash
 # CPU check of the kernel experiments kept as patches (profiles/r03_*.patch): each is applied to a scratch copy of the tree,
 # the emulated parity tests run on its source (tests/test_emulated.py, a selection) and its gfx950 assembly runs on the
-# interpreter against the oracle (tests/emu/isa/check_kernels.py). No GPU. About ten minutes.
+# interpreter against the oracle (tests/emu/isa/check_kernels.py, then 40 random configurations of fuzz_kernels.py). No GPU.
+# About half an hour.
 #   bash tools/check_archived_variants.sh > profiles/r03_archived_variants_check.txt
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -14,7 +15,9 @@ check() {   # patch, options
       echo "== $patch $* : emulated parity tests (source)" &&
       python3 -m pytest tests/test_emulated.py -q -x -p no:cacheprovider -k "radiance or llvmpipe_fixtures or primary_ids or deepest or grid_size or tile_order or several_rays" 2>&1 | tail -n 1 &&
       echo "== $patch $* : the compiled kernels on the interpreter" &&
-      python3 tests/emu/isa/check_kernels.py "$@" 2>&1 | grep -v -i warning | tail -n 4 )
+      python3 tests/emu/isa/check_kernels.py "$@" 2>&1 | grep -v -i warning | tail -n 4 &&
+      echo "== $patch $* : random configurations on the interpreter" &&
+      python3 tests/emu/isa/fuzz_kernels.py --cases 40 --seed 21 "$@" 2>&1 | tail -n 1 )
     git -C "$ROOT" worktree remove --force "$tmp/tree"; rm -rf "$tmp"
 }
 check r03_gather_memory_lanes.patch -DRT_GLOBAL_AT=16
